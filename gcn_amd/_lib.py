@@ -1,0 +1,96 @@
+"""ctypes binding of ``libgcn_hip.so`` (declarations mirror ``include/gcn_hip.h``).
+
+The library is the only compute path of this package: if it is missing, or a
+call fails, an exception is raised -- there is no CPU fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgcn_hip.so')
+
+GCN_OK = 0
+GCN_ERR_BAD_ARG = 1
+GCN_ERR_INDEX_RANGE = 2
+GCN_ERR_HIP = 3
+GCN_ERR_WORKSPACE = 4
+
+GCN_ADD_SELF_LOOPS = 1
+GCN_BINARY = 2
+GCN_RELU = 1
+GCN_NORM_SYM = 0
+GCN_NORM_RW = 1
+
+_i64 = ctypes.c_int64
+_u64 = ctypes.c_uint64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_pi64 = ctypes.POINTER(ctypes.c_int64)
+_psz = ctypes.POINTER(ctypes.c_size_t)
+
+# name -> argtypes, in header order.  tests/test_abi.py checks this table against the header.
+SIGNATURES = {
+    'gcn_version': [],
+    'gcn_last_error_string': [],
+    'gcn_coo_to_csr_bound': [_i64, _i64, _int, _pi64, _psz],
+    'gcn_coo_to_csr': [_i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    'gcn_rows_to_indptr': [_i64, _i64, _vp, _vp, _vp],
+    'gcn_row_sums': [_i64, _vp, _vp, _vp, _vp],
+    'gcn_degree_scale': [_i64, _vp, _int, _vp, _vp],
+    'gcn_normalize_adj': [_i64, _i64, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp],
+    'gcn_csr_transpose_bound': [_i64, _i64, _i64, _psz],
+    'gcn_csr_transpose': [_i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    'gcn_check_indices': [_i64, _vp, _i64, _vp],
+    'gcn_rmat_csr_bound': [_int, _int, _pi64, _psz],
+    'gcn_rmat_csr': [_int, _int, _u64, _vp, _vp, _vp, _vp, _sz, _vp],
+    'gcn_fill_synthetic_f32': [_i64, _u64, _vp, _vp],
+    'gcn_spmm_plan_create': [_i64, _i64, _i64, _vp, ctypes.POINTER(_vp), _vp],
+    'gcn_spmm_plan_destroy': [_vp],
+    'gcn_spmm_plan_info': [_vp, _pi64],
+    'gcn_spmm_plan_workspace_bytes': [_vp, _i64, _psz],
+    'gcn_spmm_csr_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _sz, _vp],
+    'gcn_spmm_csr_dropout_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64,
+                                 _vp, _sz, _vp],
+    'gcn_dropout_f32': [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _f32, _u64, _u64, _vp],
+    'gcn_gemm_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp],
+}
+
+_lib = None
+
+
+class GcnHipError(RuntimeError):
+    """A HIP call or kernel launch inside libgcn_hip.so failed."""
+
+
+def load():
+    """Load the shared library (once) and declare every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'gcn_amd: %s is not built. Run `make -C gcn_amd/csrc` (or __graft_entry__.build()). '
+            'There is no CPU fallback for the HIP path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == 'gcn_last_error_string' else ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(status):
+    """Turn a gcn_status into the exception the reference's callers would see."""
+    if status == GCN_OK:
+        return
+    msg = load().gcn_last_error_string().decode('utf-8', 'replace')
+    if status in (GCN_ERR_BAD_ARG, GCN_ERR_INDEX_RANGE, GCN_ERR_WORKSPACE):
+        raise ValueError('libgcn_hip: ' + msg)
+    raise GcnHipError('libgcn_hip: ' + msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

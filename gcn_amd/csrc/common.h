@@ -1,0 +1,55 @@
+// Shared host/device helpers of libgcn_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gcn_hip.h"
+
+namespace gcn {
+
+// ---- per-thread error text behind gcn_last_error_string() --------------------------------
+void set_error(const char* fmt, ...);
+int fail(gcn_status code, const char* fmt, ...);
+
+#define GCN_HIP_TRY(expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return ::gcn::fail(GCN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                               __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define GCN_LAUNCH_CHECK()                                                                                  \
+    do {                                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                                 \
+        if (e__ != hipSuccess)                                                                              \
+            return ::gcn::fail(GCN_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, \
+                               __LINE__);                                                                   \
+    } while (0)
+
+// ---- counter-based random numbers: identical integer arithmetic on host, device and in the CPU oracle ----
+__host__ __device__ __forceinline__ uint64_t sm64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// key of the random stream (seed, stream_id); computed once on the host per call
+__host__ __device__ __forceinline__ uint64_t stream_key(uint64_t seed, uint64_t stream_id) {
+    return sm64(sm64(seed) ^ stream_id);
+}
+// 24 random bits -> u in [0,1), exactly representable in float32
+__device__ __forceinline__ float uniform24(uint64_t key, uint64_t idx) {
+    return (float)(uint32_t)(sm64(key ^ idx) >> 40) * 5.9604644775390625e-08f;  // 2^-24
+}
+// dropout predicate of gcn/layers.py:21-23: floor(keep_prob + u) == 1, evaluated in float32
+__device__ __forceinline__ bool keep_entry(uint64_t key, uint64_t idx, float keep_prob) {
+    return floorf(__fadd_rn(keep_prob, uniform24(key, idx))) >= 1.0f;
+}
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace gcn

@@ -1,0 +1,528 @@
+// Graph preprocessing for the GCN propagation path: COO -> CSR with self-loops, row sums,
+// D^-1/2 scaling, stable transpose, R-MAT generation.  Integer kernels; the float64 scaling
+// follows gcn/utils.py:297-323 operation by operation.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace gcn {
+
+constexpr uint64_t kInvalidKey = ~0ull;
+constexpr int kBlock = 256;
+
+static inline unsigned bits_for(uint64_t v) {  // number of bits needed to hold values in [0, v]
+    unsigned b = 0;
+    while (v) {
+        ++b;
+        v >>= 1;
+    }
+    return b ? b : 1;
+}
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)ceil_div(n > 0 ? n : 1, kBlock)); }
+
+// ------------------------------------------------------------------------------------------------
+// sorted keys (row << 32 | col) -> CSR, merging equal keys
+// ------------------------------------------------------------------------------------------------
+__global__ void head_flags_kernel(int64_t m, const uint64_t* __restrict__ keys, int64_t* __restrict__ pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t k = keys[i];
+    pos[i] = (k != kInvalidKey && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+// pos holds the EXCLUSIVE scan of the head flags.  One thread per sorted element; heads write.
+// mode 0: value = sum of vals over the run; mode 1: value = run length; mode 2: no value (binary)
+__global__ void scatter_unique_kernel(int64_t m, int64_t n_rows, const uint64_t* __restrict__ keys,
+                                      const double* __restrict__ vals, const int64_t* __restrict__ pos, int mode,
+                                      int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
+                                      double* __restrict__ vals_out, int64_t* __restrict__ nnz_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t k = keys[i];
+    if (k == kInvalidKey) {
+        if (i == 0) {  // no valid entry at all
+            for (int64_t q = 0; q <= n_rows; ++q) indptr[q] = 0;
+            *nnz_out = 0;
+        }
+        return;
+    }
+    const int64_t row = (int64_t)(k >> 32);
+    const bool head = (i == 0) || (keys[i - 1] != k);
+    const int64_t j = pos[i] - (head ? 0 : 1);  // index of this element's unique entry
+    if (head) {
+        indices[j] = (int32_t)(uint32_t)k;
+        if (mode != 2) {
+            double s = (mode == 0) ? vals[i] : 1.0;
+            for (int64_t t = i + 1; t < m && keys[t] == k; ++t) s += (mode == 0) ? vals[t] : 1.0;
+            vals_out[j] = s;
+        }
+        const int64_t prev_row = (i == 0) ? -1 : (int64_t)(keys[i - 1] >> 32);
+        for (int64_t q = prev_row + 1; q <= row; ++q) indptr[q] = j;  // rows that start here (and empty ones before)
+    }
+    const bool last = (i == m - 1) || (keys[i + 1] == kInvalidKey);
+    if (last) {
+        const int64_t total = j + 1;
+        for (int64_t q = row + 1; q <= n_rows; ++q) indptr[q] = total;
+        *nnz_out = total;
+    }
+}
+
+struct SortScratch {
+    uint64_t* keys_a;
+    uint64_t* keys_b;
+    double* vals_a;
+    double* vals_b;
+    int64_t* pos;
+    void* prim;
+    size_t prim_bytes;
+};
+
+static size_t prim_temp_bytes(int64_t m, bool valued) {
+    size_t a = 0, b = 0;
+    rocprim::double_buffer<uint64_t> kd(nullptr, nullptr);
+    if (valued) {
+        rocprim::double_buffer<double> vd(nullptr, nullptr);
+        (void)rocprim::radix_sort_pairs(nullptr, a, kd, vd, (size_t)m, 0u, 64u, (hipStream_t)0);
+    } else {
+        (void)rocprim::radix_sort_keys(nullptr, a, kd, (size_t)m, 0u, 64u, (hipStream_t)0);
+    }
+    (void)rocprim::exclusive_scan(nullptr, b, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)m,
+                                  rocprim::plus<int64_t>(), (hipStream_t)0);
+    return align_up(a > b ? a : b, 256) + 256;
+}
+
+static size_t sort_scratch_bytes(int64_t m, bool valued) {
+    const size_t seg = align_up((size_t)(m > 0 ? m : 1) * 8, 256);
+    return seg * (valued ? 5 : 3) + prim_temp_bytes(m, valued);
+}
+
+static int carve_scratch(void* workspace, size_t workspace_bytes, int64_t m, bool valued, SortScratch* s) {
+    const size_t need = sort_scratch_bytes(m, valued);
+    if (workspace == nullptr || workspace_bytes < need)
+        return fail(GCN_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    if (((uintptr_t)workspace & 255) != 0) return fail(GCN_ERR_BAD_ARG, "workspace must be 256-byte aligned");
+    const size_t seg = align_up((size_t)(m > 0 ? m : 1) * 8, 256);
+    char* p = (char*)workspace;
+    s->keys_a = (uint64_t*)p;
+    p += seg;
+    s->keys_b = (uint64_t*)p;
+    p += seg;
+    s->pos = (int64_t*)p;
+    p += seg;
+    s->vals_a = s->vals_b = nullptr;
+    if (valued) {
+        s->vals_a = (double*)p;
+        p += seg;
+        s->vals_b = (double*)p;
+        p += seg;
+    }
+    s->prim = p;
+    s->prim_bytes = prim_temp_bytes(m, valued);
+    return GCN_OK;
+}
+
+// keys (and values) sit in scratch->keys_a / vals_a; sorts, merges, writes the CSR.
+static int sorted_merge_to_csr(SortScratch* s, int64_t m, bool valued, int mode, unsigned key_bits, int64_t n_rows,
+                               int64_t* indptr, int32_t* indices, double* vals_out, int64_t* nnz_out,
+                               hipStream_t st) {
+    if (m == 0) {
+        GCN_HIP_TRY(hipMemsetAsync(indptr, 0, (size_t)(n_rows + 1) * 8, st));
+        GCN_HIP_TRY(hipMemsetAsync(nnz_out, 0, 8, st));
+        return GCN_OK;
+    }
+    rocprim::double_buffer<uint64_t> kd(s->keys_a, s->keys_b);
+    size_t tb = s->prim_bytes;
+    const double* sorted_vals = nullptr;
+    if (valued) {
+        rocprim::double_buffer<double> vd(s->vals_a, s->vals_b);
+        GCN_HIP_TRY(rocprim::radix_sort_pairs(s->prim, tb, kd, vd, (size_t)m, 0u, key_bits, st));
+        sorted_vals = vd.current();
+    } else {
+        // invalid keys are all ones: they need the full 64 bits to sort to the end
+        GCN_HIP_TRY(rocprim::radix_sort_keys(s->prim, tb, kd, (size_t)m, 0u, key_bits, st));
+    }
+    const uint64_t* sorted = kd.current();
+    head_flags_kernel<<<grid_for(m), kBlock, 0, st>>>(m, sorted, s->pos);
+    GCN_LAUNCH_CHECK();
+    tb = s->prim_bytes;
+    GCN_HIP_TRY(rocprim::exclusive_scan(s->prim, tb, s->pos, s->pos, (int64_t)0, (size_t)m, rocprim::plus<int64_t>(),
+                                        st));
+    scatter_unique_kernel<<<grid_for(m), kBlock, 0, st>>>(m, n_rows, sorted, sorted_vals, s->pos, mode, indptr,
+                                                          indices, vals_out, nnz_out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+__global__ void pack_coo_keys_kernel(int64_t nnz_in, int64_t n_loops, const int32_t* __restrict__ rows,
+                                     const int32_t* __restrict__ cols, const double* __restrict__ vals,
+                                     uint64_t* __restrict__ keys, double* __restrict__ kvals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnz_in + n_loops) return;
+    if (i < nnz_in) {
+        keys[i] = ((uint64_t)(uint32_t)rows[i] << 32) | (uint32_t)cols[i];
+        if (kvals) kvals[i] = vals ? vals[i] : 1.0;
+    } else {
+        const uint64_t d = (uint64_t)(i - nnz_in);
+        keys[i] = (d << 32) | d;  // the sp.eye(n) entry
+        if (kvals) kvals[i] = 1.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-grouped triple -> indptr
+// ------------------------------------------------------------------------------------------------
+__global__ void rows_to_indptr_kernel(int64_t n_rows, int64_t nnz, const int32_t* __restrict__ rows,
+                                      int64_t* __restrict__ indptr) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int64_t r = rows[k];
+    const int64_t rp = (k == 0) ? -1 : (int64_t)rows[k - 1];
+    for (int64_t q = rp + 1; q <= r; ++q) indptr[q] = k;
+    if (k == nnz - 1)
+        for (int64_t q = r + 1; q <= n_rows; ++q) indptr[q] = nnz;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row sums, degree scaling, normalisation
+// ------------------------------------------------------------------------------------------------
+__global__ void row_sums_kernel(int64_t n_rows, const int64_t* __restrict__ indptr, const double* __restrict__ vals,
+                                double* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t k0 = indptr[r], k1 = indptr[r + 1];
+    double s = 0.0;
+    if (vals) {
+        for (int64_t k = k0; k < k1; ++k) s += vals[k];  // storage order, like the reference's sum(1)
+    } else {
+        s = (double)(k1 - k0);
+    }
+    out[r] = s;
+}
+
+// x^-0.5 to (all but provably) correct rounding: 1/sqrt(x) refined by one Newton step whose
+// residual is evaluated with an exact product split, so the result agrees with a correctly
+// rounded pow(x, -0.5).
+__device__ __forceinline__ double inv_sqrt_rn(double x) {
+    const double y0 = 1.0 / sqrt(x);
+    const double t_hi = x * y0;
+    const double t_lo = fma(x, y0, -t_hi);
+    const double e = fma(-t_hi, y0, 1.0) - t_lo * y0;  // 1 - x*y0^2
+    return fma(0.5 * y0, e, y0);
+}
+
+__global__ void degree_scale_kernel(int64_t n, const double* __restrict__ rowsum, int type, double* __restrict__ d) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const double x = rowsum[r];
+    double y;
+    if (type == GCN_NORM_SYM) {
+        y = (x > 0.0) ? inv_sqrt_rn(x) : ((x == 0.0) ? 0.0 : __longlong_as_double(0x7ff8000000000000ll));
+    } else {
+        y = (x != 0.0) ? 1.0 / x : 0.0;
+    }
+    if (isinf(y)) y = 0.0;
+    d[r] = y;
+}
+
+__device__ __forceinline__ int64_t row_of_entry(const int64_t* __restrict__ indptr, int64_t n_rows, int64_t k) {
+    // largest r with indptr[r] <= k
+    int64_t lo = 0, hi = n_rows;  // invariant: indptr[lo] <= k < indptr[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] <= k)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ void normalize_kernel(int64_t n_rows, int64_t nnz, const int64_t* __restrict__ indptr,
+                                 const int32_t* __restrict__ indices, const double* __restrict__ vals,
+                                 const double* __restrict__ d, int type, double* __restrict__ out64,
+                                 float* __restrict__ out32) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int64_t r = row_of_entry(indptr, n_rows, k);
+    const double a = vals ? vals[k] : 1.0;
+    double w;
+    if (type == GCN_NORM_SYM) {
+        // adj.dot(D).transpose().dot(D): the stored (r, c) entry becomes result[c, r] = (a * d[c]) * d[r]
+        const double t = __dmul_rn(a, d[indices[k]]);
+        w = __dmul_rn(t, d[r]);
+    } else {
+        w = __dmul_rn(d[r], a);
+    }
+    if (out64) out64[k] = w;
+    if (out32) out32[k] = (float)w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stable transpose
+// ------------------------------------------------------------------------------------------------
+__global__ void transpose_keys_kernel(int64_t nnz, const int32_t* __restrict__ indices, uint32_t* __restrict__ keys,
+                                      int64_t* __restrict__ src) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    keys[k] = (uint32_t)indices[k];
+    src[k] = k;
+}
+
+__global__ void transpose_scatter_kernel(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                                         const int64_t* __restrict__ indptr, const uint32_t* __restrict__ keys,
+                                         const int64_t* __restrict__ src, const void* __restrict__ vals, int val_bytes,
+                                         int64_t* __restrict__ t_indptr, int32_t* __restrict__ t_indices,
+                                         void* __restrict__ t_vals, int64_t* __restrict__ perm) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nnz) return;
+    const int64_t k = src[j];
+    t_indices[j] = (int32_t)row_of_entry(indptr, n_rows, k);
+    if (val_bytes == 4) ((float*)t_vals)[j] = ((const float*)vals)[k];
+    if (val_bytes == 8) ((double*)t_vals)[j] = ((const double*)vals)[k];
+    if (perm) perm[j] = k;
+    const int64_t c = keys[j];
+    const int64_t cp = (j == 0) ? -1 : (int64_t)keys[j - 1];
+    for (int64_t q = cp + 1; q <= c; ++q) t_indptr[q] = j;
+    if (j == nnz - 1)
+        for (int64_t q = c + 1; q <= n_cols; ++q) t_indptr[q] = nnz;
+}
+
+static size_t transpose_prim_bytes(int64_t nnz) {
+    size_t a = 0;
+    rocprim::double_buffer<uint32_t> kd(nullptr, nullptr);
+    rocprim::double_buffer<int64_t> vd(nullptr, nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, a, kd, vd, (size_t)nnz, 0u, 32u, (hipStream_t)0);
+    return align_up(a, 256) + 256;
+}
+
+// ------------------------------------------------------------------------------------------------
+// index range check
+// ------------------------------------------------------------------------------------------------
+__global__ void check_indices_kernel(int64_t nnz, const int32_t* __restrict__ indices, int64_t n_cols,
+                                     int* __restrict__ bad) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int64_t c = indices[k];
+    if (c < 0 || c >= n_cols) atomicOr(bad, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// R-MAT and synthetic features
+// ------------------------------------------------------------------------------------------------
+__global__ void rmat_keys_kernel(int scale, int64_t n_pairs, uint64_t key, uint32_t ta, uint32_t tb, uint32_t tc,
+                                 uint64_t* __restrict__ keys) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_pairs) return;
+    uint64_t u = 0, v = 0;
+    for (int level = 0; level < scale; ++level) {
+        const uint32_t r = (uint32_t)(sm64(key ^ ((uint64_t)e * (uint64_t)scale + (uint64_t)level)) >> 32);
+        const uint32_t q = (r >= ta) + (r >= tb) + (r >= tc);
+        u = (u << 1) | (q >> 1);
+        v = (v << 1) | (q & 1);
+    }
+    const bool loop = (u == v);
+    keys[2 * e] = loop ? kInvalidKey : ((u << 32) | v);
+    keys[2 * e + 1] = loop ? kInvalidKey : ((v << 32) | u);
+}
+
+__global__ void fill_synthetic_kernel(int64_t count, uint64_t key, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int32_t hi = (int32_t)(uint32_t)(sm64(key ^ (uint64_t)i) >> 32);
+    out[i] = (float)(hi >> 8) * 1.1920928955078125e-07f;  // 2^-23
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+extern "C" {
+
+int gcn_coo_to_csr_bound(int64_t n_rows, int64_t nnz_in, int flags, int64_t* nnz_capacity, size_t* workspace_bytes) {
+    if (n_rows < 0 || nnz_in < 0 || !nnz_capacity || !workspace_bytes) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    const int64_t m = nnz_in + ((flags & GCN_ADD_SELF_LOOPS) ? n_rows : 0);
+    *nnz_capacity = m > 0 ? m : 1;
+    *workspace_bytes = sort_scratch_bytes(m, !(flags & GCN_BINARY));
+    return GCN_OK;
+}
+
+int gcn_coo_to_csr(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const int32_t* rows, const int32_t* cols,
+                   const double* vals, int flags, int64_t* indptr_out, int32_t* indices_out, double* vals_out,
+                   int64_t* nnz_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_rows < 0 || n_cols < 0 || nnz_in < 0 || n_rows > INT32_MAX || n_cols > INT32_MAX)
+        return fail(GCN_ERR_BAD_ARG, "bad shape %lld x %lld, nnz %lld", (long long)n_rows, (long long)n_cols,
+                    (long long)nnz_in);
+    if ((nnz_in > 0 && (!rows || !cols)) || !indptr_out || !indices_out || !nnz_out)
+        return fail(GCN_ERR_BAD_ARG, "null pointer");
+    const bool binary = (flags & GCN_BINARY) != 0;
+    if (!binary && !vals_out) return fail(GCN_ERR_BAD_ARG, "vals_out is required unless GCN_BINARY is set");
+    if ((flags & GCN_ADD_SELF_LOOPS) && n_rows != n_cols)
+        return fail(GCN_ERR_BAD_ARG, "self-loops need a square matrix");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_loops = (flags & GCN_ADD_SELF_LOOPS) ? n_rows : 0;
+    const int64_t m = nnz_in + n_loops;
+    const bool valued = !binary;
+    SortScratch s;
+    int rc = carve_scratch(workspace, workspace_bytes, m, valued, &s);
+    if (rc != GCN_OK) return rc;
+    if (m > 0) {
+        pack_coo_keys_kernel<<<grid_for(m), kBlock, 0, st>>>(nnz_in, n_loops, rows, cols, vals, s.keys_a,
+                                                             valued ? s.vals_a : nullptr);
+        GCN_LAUNCH_CHECK();
+    }
+    const unsigned key_bits = 32 + bits_for((uint64_t)(n_rows > 0 ? n_rows - 1 : 0));
+    return sorted_merge_to_csr(&s, m, valued, binary ? 2 : 0, key_bits, n_rows, indptr_out, indices_out, vals_out,
+                               nnz_out, st);
+}
+
+int gcn_rows_to_indptr(int64_t n_rows, int64_t nnz, const int32_t* rows, int64_t* indptr_out, void* stream) {
+    if (n_rows < 0 || nnz < 0 || !indptr_out || (nnz > 0 && !rows)) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (nnz == 0) {
+        GCN_HIP_TRY(hipMemsetAsync(indptr_out, 0, (size_t)(n_rows + 1) * 8, st));
+        return GCN_OK;
+    }
+    rows_to_indptr_kernel<<<grid_for(nnz), kBlock, 0, st>>>(n_rows, nnz, rows, indptr_out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_row_sums(int64_t n_rows, const int64_t* indptr, const double* vals, double* rowsum_out, void* stream) {
+    if (n_rows < 0 || !indptr || !rowsum_out) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (n_rows == 0) return GCN_OK;
+    row_sums_kernel<<<grid_for(n_rows), kBlock, 0, (hipStream_t)stream>>>(n_rows, indptr, vals, rowsum_out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_degree_scale(int64_t n_rows, const double* rowsum, int type, double* d_out, void* stream) {
+    if (n_rows < 0 || !rowsum || !d_out || (type != GCN_NORM_SYM && type != GCN_NORM_RW))
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (n_rows == 0) return GCN_OK;
+    degree_scale_kernel<<<grid_for(n_rows), kBlock, 0, (hipStream_t)stream>>>(n_rows, rowsum, type, d_out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_normalize_adj(int64_t n_rows, int64_t nnz, const int64_t* indptr, const int32_t* indices, const double* vals,
+                      const double* d, int type, double* vals64_out, float* vals32_out, void* stream) {
+    if (n_rows < 0 || nnz < 0 || !indptr || !d || (nnz > 0 && !indices) ||
+        (type != GCN_NORM_SYM && type != GCN_NORM_RW))
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (nnz == 0) return GCN_OK;
+    normalize_kernel<<<grid_for(nnz), kBlock, 0, (hipStream_t)stream>>>(n_rows, nnz, indptr, indices, vals, d, type,
+                                                                        vals64_out, vals32_out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_csr_transpose_bound(int64_t n_rows, int64_t n_cols, int64_t nnz, size_t* workspace_bytes) {
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || !workspace_bytes) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    const size_t n = (size_t)(nnz > 0 ? nnz : 1);
+    *workspace_bytes = 2 * align_up(n * 4, 256) + 2 * align_up(n * 8, 256) + transpose_prim_bytes(nnz);
+    return GCN_OK;
+}
+
+int gcn_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                      const void* vals, int val_bytes, int64_t* t_indptr, int32_t* t_indices, void* t_vals,
+                      int64_t* perm_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || n_rows > INT32_MAX || n_cols > INT32_MAX || !indptr || !t_indptr ||
+        (nnz > 0 && (!indices || !t_indices)))
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (val_bytes != 0 && val_bytes != 4 && val_bytes != 8) return fail(GCN_ERR_BAD_ARG, "val_bytes must be 0, 4 or 8");
+    if (val_bytes != 0 && nnz > 0 && (!vals || !t_vals)) return fail(GCN_ERR_BAD_ARG, "null value pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (nnz == 0) {
+        GCN_HIP_TRY(hipMemsetAsync(t_indptr, 0, (size_t)(n_cols + 1) * 8, st));
+        return GCN_OK;
+    }
+    size_t need = 0;
+    gcn_csr_transpose_bound(n_rows, n_cols, nnz, &need);
+    if (!workspace || workspace_bytes < need)
+        return fail(GCN_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    if (((uintptr_t)workspace & 255) != 0) return fail(GCN_ERR_BAD_ARG, "workspace must be 256-byte aligned");
+    char* p = (char*)workspace;
+    uint32_t* ka = (uint32_t*)p;
+    p += align_up((size_t)nnz * 4, 256);
+    uint32_t* kb = (uint32_t*)p;
+    p += align_up((size_t)nnz * 4, 256);
+    int64_t* va = (int64_t*)p;
+    p += align_up((size_t)nnz * 8, 256);
+    int64_t* vb = (int64_t*)p;
+    p += align_up((size_t)nnz * 8, 256);
+    size_t tb = transpose_prim_bytes(nnz);
+    transpose_keys_kernel<<<grid_for(nnz), kBlock, 0, st>>>(nnz, indices, ka, va);
+    GCN_LAUNCH_CHECK();
+    rocprim::double_buffer<uint32_t> kd(ka, kb);
+    rocprim::double_buffer<int64_t> vd(va, vb);
+    const unsigned bits = bits_for((uint64_t)(n_cols > 0 ? n_cols - 1 : 0));
+    GCN_HIP_TRY(rocprim::radix_sort_pairs(p, tb, kd, vd, (size_t)nnz, 0u, bits, st));
+    transpose_scatter_kernel<<<grid_for(nnz), kBlock, 0, st>>>(n_rows, n_cols, nnz, indptr, kd.current(),
+                                                               vd.current(), vals, val_bytes, t_indptr, t_indices,
+                                                               t_vals, perm_out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_check_indices(int64_t nnz, const int32_t* indices, int64_t n_cols, void* stream) {
+    if (nnz < 0 || (nnz > 0 && !indices)) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (nnz == 0) return GCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int* flag = nullptr;
+    GCN_HIP_TRY(hipMalloc(&flag, sizeof(int)));
+    int host = 0;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
+    if (e == hipSuccess) {
+        check_indices_kernel<<<grid_for(nnz), kBlock, 0, st>>>(nnz, indices, n_cols, flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(flag);
+    if (e != hipSuccess) return fail(GCN_ERR_HIP, "index check failed: %s", hipGetErrorString(e));
+    if (host) return fail(GCN_ERR_INDEX_RANGE, "a column index is outside [0, %lld)", (long long)n_cols);
+    return GCN_OK;
+}
+
+int gcn_rmat_csr_bound(int scale, int edge_factor, int64_t* nnz_capacity, size_t* workspace_bytes) {
+    if (scale < 1 || scale > 30 || edge_factor < 1 || !nnz_capacity || !workspace_bytes)
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    const int64_t m = 2 * ((int64_t)edge_factor << scale);
+    *nnz_capacity = m;
+    *workspace_bytes = sort_scratch_bytes(m, false);
+    return GCN_OK;
+}
+
+int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int64_t* indptr_out, int32_t* indices_out,
+                 int64_t* nnz_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (scale < 1 || scale > 30 || edge_factor < 1 || !indptr_out || !indices_out || !nnz_out)
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_pairs = (int64_t)edge_factor << scale;
+    const int64_t m = 2 * n_pairs;
+    SortScratch s;
+    int rc = carve_scratch(workspace, workspace_bytes, m, false, &s);
+    if (rc != GCN_OK) return rc;
+    const uint32_t ta = (uint32_t)(0.57 * 4294967296.0);
+    const uint32_t tb = (uint32_t)((0.57 + 0.19) * 4294967296.0);
+    const uint32_t tc = (uint32_t)((0.57 + 0.19 + 0.19) * 4294967296.0);
+    rmat_keys_kernel<<<grid_for(n_pairs), kBlock, 0, st>>>(scale, n_pairs, stream_key(seed, 0), ta, tb, tc, s.keys_a);
+    GCN_LAUNCH_CHECK();
+    // invalid keys are all ones and must sort last: sort on all 64 bits
+    return sorted_merge_to_csr(&s, m, false, 2, 64u, (int64_t)1 << scale, indptr_out, indices_out, nullptr, nnz_out,
+                               st);
+}
+
+int gcn_fill_synthetic_f32(int64_t count, uint64_t seed, float* out, void* stream) {
+    if (count < 0 || (count > 0 && !out)) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (count == 0) return GCN_OK;
+    fill_synthetic_kernel<<<grid_for(count), kBlock, 0, (hipStream_t)stream>>>(count, stream_key(seed, 0), out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,548 @@
+// CSR x dense products of the GCN layer: A_hat.(XW) (gcn/layers.py:202) and X'.W0 with fused
+// sparse dropout (gcn/layers.py:19-25, 198-199).  HBM-bound gather kernels for gfx950.
+//
+// Work decomposition
+//   strips : the nnz axis is cut every kStripNnz entries; a wave owns the rows that START inside its
+//            strip, so waves carry equal work however skewed the degrees are.  Inside a wave, groups
+//            of LPR lanes own one row each; a lane holds VPL vectors of VEC floats of that row.
+//   chunks : rows longer than kSplitNnz are left out of the strips, cut in chunks of kSplitNnz
+//            entries, each chunk summed by one lane group into a partial row, and the partial rows
+//            of a row are added in chunk order by a third kernel.
+// Every row of at most kSplitNnz entries is therefore accumulated sequentially in storage order with
+// a separate multiply and add (this file is compiled with -ffp-contract=off): bit-identical to the
+// serial CPU loop.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+struct gcn_spmm_plan {
+    int64_t n_rows, n_cols, nnz;
+    int64_t n_strips, n_long, n_chunks;
+    int device;
+    int32_t* strip_row;   // [n_strips + 1] first row starting in each strip
+    int32_t* long_row;    // [n_long] rows longer than kSplitNnz, ascending
+    int64_t* long_chunk;  // [n_long + 1] first chunk of each long row
+    int32_t* chunk_long;  // [n_chunks] long-row slot of each chunk
+};
+
+namespace gcn {
+
+constexpr int kStripNnz = 256;
+constexpr int kSplitNnz = 1024;
+constexpr int kBlock = 256;
+constexpr int kUnroll = 4;
+
+// ------------------------------------------------------------------------------------------------
+// plan kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void strip_rows_kernel(int64_t n_rows, const int64_t* __restrict__ indptr, int64_t n_strips,
+                                  int32_t* __restrict__ strip_row) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > n_strips) return;
+    if (w == n_strips) {
+        strip_row[w] = (int32_t)n_rows;  // trailing empty rows belong to the last strip
+        return;
+    }
+    const int64_t target = w * kStripNnz;
+    int64_t lo = 0, hi = n_rows;  // smallest r in [0, n_rows] with indptr[r] >= target
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] >= target)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    strip_row[w] = (int32_t)lo;
+}
+
+__global__ void collect_long_rows_kernel(int64_t n_rows, const int64_t* __restrict__ indptr, int64_t capacity,
+                                         int32_t* __restrict__ rows, int64_t* __restrict__ starts,
+                                         int64_t* __restrict__ ends, unsigned long long* __restrict__ counter) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t k0 = indptr[r], k1 = indptr[r + 1];
+    if (k1 - k0 > kSplitNnz) {
+        const unsigned long long slot = atomicAdd(counter, 1ull);
+        if ((int64_t)slot < capacity) {
+            rows[slot] = (int32_t)r;
+            starts[slot] = k0;
+            ends[slot] = k1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// product kernels
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> {
+    using type = float;
+};
+template <>
+struct VecT<4> {
+    using type = float4;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&out)[VEC]);
+template <>
+__device__ __forceinline__ void load_vec<1>(const float* p, float (&out)[1]) {
+    out[0] = *p;
+}
+template <>
+__device__ __forceinline__ void load_vec<4>(const float* p, float (&out)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    out[0] = v.x;
+    out[1] = v.y;
+    out[2] = v.z;
+    out[3] = v.w;
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]);
+template <>
+__device__ __forceinline__ void store_vec<1>(float* p, const float (&v)[1]) {
+    *p = v[0];
+}
+template <>
+__device__ __forceinline__ void store_vec<4>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+struct DropArgs {
+    const int64_t* perm;
+    uint64_t key;
+    float keep_prob;
+    float inv_keep;
+};
+
+// acc += sum over entries k0..k1-1 (in order) of a_k * B[col_k, this lane's columns].
+// Entries are taken kUnroll at a time: the B rows of one batch and the (index, value) pairs of the
+// next batch are all in flight together.  Addresses past the end of the range are clamped to its
+// last entry (a valid, cached address) so that no load sits behind a branch; what such a slot
+// loads is never added.
+template <int VEC, int VPL, bool DROPOUT>
+__device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const int32_t* __restrict__ indices,
+                                                 const float* __restrict__ vals, const float* __restrict__ b,
+                                                 uint32_t ldb, const int (&lcol)[VPL], const DropArgs& dr,
+                                                 float (&acc)[VPL][VEC]) {
+    if (k0 >= k1) return;
+    const int64_t k_last = k1 - 1;
+    uint32_t c[kUnroll];
+    float a[kUnroll];
+    int64_t id[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+        const int64_t ku = (k0 + u < k_last) ? k0 + u : k_last;
+        c[u] = (uint32_t)indices[ku];
+        a[u] = vals[ku];
+        if (DROPOUT) id[u] = dr.perm ? dr.perm[ku] : ku;
+    }
+    for (int64_t k = k0;; k += kUnroll) {
+        float bv[kUnroll][VPL][VEC];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const float* brow = b + (uint64_t)c[u] * (uint64_t)ldb;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) load_vec<VEC>(brow + lcol[v], bv[u][v]);
+        }
+        float a_now[kUnroll];
+        bool kept[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            a_now[u] = a[u];
+            kept[u] = true;
+            if (DROPOUT) {
+                kept[u] = keep_entry(dr.key, (uint64_t)id[u], dr.keep_prob);
+                a_now[u] = __fmul_rn(a[u], dr.inv_keep);
+            }
+        }
+        // (index, value) pairs of the next batch
+        const int64_t kn = k + kUnroll;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t ku = (kn + u < k_last) ? kn + u : k_last;
+            c[u] = (uint32_t)indices[ku];
+            a[u] = vals[ku];
+            if (DROPOUT) id[u] = dr.perm ? dr.perm[ku] : ku;
+        }
+        const int64_t rem = k1 - k;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (u < rem && kept[u]) {
+#pragma unroll
+                for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[v][e] = __fadd_rn(acc[v][e], __fmul_rn(a_now[u], bv[u][v][e]));
+            }
+        }
+        if (rem <= kUnroll) break;
+    }
+}
+
+template <int VEC, int VPL>
+__device__ __forceinline__ void store_row(float* dst, const int (&col)[VPL], const bool (&on)[VPL],
+                                          float (&acc)[VPL][VEC], bool relu) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+        if (on[v]) {
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[v][e] = acc[v][e] > 0.0f ? acc[v][e] : 0.0f;
+            }
+            store_vec<VEC>(dst + col[v], acc[v]);
+        }
+}
+
+// rows of ordinary length; one wave per strip
+template <int LPR, int VEC, int VPL, bool DROPOUT>
+__global__ __launch_bounds__(kBlock) void spmm_strips_kernel(
+    int64_t n_strips, const int32_t* __restrict__ strip_row, const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ indices, const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
+    uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu, DropArgs dr) {
+    constexpr int kGroups = 64 / LPR;
+    constexpr int kTile = LPR * VEC * VPL;  // columns covered per pass
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int64_t strip = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (strip >= n_strips) return;
+    const int r_lo = strip_row[strip];
+    const int r_hi = strip_row[strip + 1];
+    for (int64_t col0 = 0; col0 < f; col0 += kTile) {
+        int col[VPL];   // first column of each of this lane's vectors
+        int lcol[VPL];  // the column it loads from: clamped into the row so that idle lanes load valid data
+        bool on[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            col[v] = (int)col0 + (v * LPR + sub) * VEC;
+            on[v] = col[v] < f;
+            lcol[v] = on[v] ? col[v] : (int)f - VEC;
+        }
+        for (int r = r_lo + grp; r < r_hi; r += kGroups) {
+            const int64_t k0 = indptr[r];
+            const int64_t k1 = indptr[r + 1];
+            if (k1 - k0 > kSplitNnz) continue;  // summed by the chunk kernels
+            float acc[VPL][VEC];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
+            accumulate_range<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
+            store_row<VEC, VPL>(c + (int64_t)r * ldc, col, on, acc, relu != 0);
+        }
+    }
+}
+
+// one lane group per chunk of a long row -> partial row in the workspace
+template <int LPR, int VEC, int VPL, bool DROPOUT>
+__global__ __launch_bounds__(kBlock) void spmm_chunks_kernel(
+    int64_t n_chunks, const int32_t* __restrict__ chunk_long, const int32_t* __restrict__ long_row,
+    const int64_t* __restrict__ long_chunk, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const float* __restrict__ vals, int64_t f, const float* __restrict__ b, uint32_t ldb, float* __restrict__ part,
+    int64_t ldp, DropArgs dr) {
+    constexpr int kGroups = 64 / LPR;
+    constexpr int kTile = LPR * VEC * VPL;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t chunk = wave * kGroups + grp;
+    if (chunk >= n_chunks) return;
+    const int li = chunk_long[chunk];
+    const int r = long_row[li];
+    const int64_t k0 = indptr[r] + (chunk - long_chunk[li]) * (int64_t)kSplitNnz;
+    const int64_t row_end = indptr[r + 1];
+    const int64_t k1 = (k0 + kSplitNnz < row_end) ? k0 + kSplitNnz : row_end;
+    for (int64_t col0 = 0; col0 < f; col0 += kTile) {
+        int col[VPL];   // first column of each of this lane's vectors
+        int lcol[VPL];  // the column it loads from: clamped into the row so that idle lanes load valid data
+        bool on[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            col[v] = (int)col0 + (v * LPR + sub) * VEC;
+            on[v] = col[v] < f;
+            lcol[v] = on[v] ? col[v] : (int)f - VEC;
+        }
+        float acc[VPL][VEC];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
+        accumulate_range<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
+        store_row<VEC, VPL>(part + chunk * ldp, col, on, acc, false);
+    }
+}
+
+// partial rows of each long row, added in chunk order; one wave per long row
+__global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(int64_t n_long, const int32_t* __restrict__ long_row,
+                                                                  const int64_t* __restrict__ long_chunk, int64_t f,
+                                                                  const float* __restrict__ part, int64_t ldp,
+                                                                  float* __restrict__ c, int64_t ldc, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int64_t li = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (li >= n_long) return;
+    const int64_t c0 = long_chunk[li], c1 = long_chunk[li + 1];
+    float* dst = c + (int64_t)long_row[li] * ldc;
+    for (int64_t j = lane; j < f; j += 64) {
+        float s = 0.0f;
+        for (int64_t ch = c0; ch < c1; ++ch) s = __fadd_rn(s, part[ch * ldp + j]);
+        if (relu) s = s > 0.0f ? s : 0.0f;
+        dst[j] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------
+struct SpmmCall {
+    const gcn_spmm_plan* plan;
+    const int64_t* indptr;
+    const int32_t* indices;
+    const float* vals;
+    int64_t f;
+    const float* b;
+    uint32_t ldb;
+    float* c;
+    int64_t ldc;
+    int relu;
+    float* part;
+    int64_t ldp;
+    DropArgs dr;
+    hipStream_t st;
+};
+
+template <int LPR, int VEC, int VPL, bool DROPOUT>
+static int launch_variant(const SpmmCall& a) {
+    const gcn_spmm_plan* p = a.plan;
+    constexpr int kWaves = kBlock / 64;
+    constexpr int kGroups = 64 / LPR;
+    {
+        const unsigned grid = (unsigned)ceil_div(p->n_strips, kWaves);
+        spmm_strips_kernel<LPR, VEC, VPL, DROPOUT><<<grid, kBlock, 0, a.st>>>(
+            p->n_strips, p->strip_row, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.relu, a.dr);
+        GCN_LAUNCH_CHECK();
+    }
+    if (p->n_chunks > 0) {
+        const unsigned grid = (unsigned)ceil_div(ceil_div(p->n_chunks, kGroups), kWaves);
+        spmm_chunks_kernel<LPR, VEC, VPL, DROPOUT><<<grid, kBlock, 0, a.st>>>(
+            p->n_chunks, p->chunk_long, p->long_row, p->long_chunk, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb,
+            a.part, a.ldp, a.dr);
+        GCN_LAUNCH_CHECK();
+        const unsigned grid2 = (unsigned)ceil_div(p->n_long, kWaves);
+        spmm_long_reduce_kernel<<<grid2, kBlock, 0, a.st>>>(p->n_long, p->long_row, p->long_chunk, a.f, a.part,
+                                                            a.ldp, a.c, a.ldc, a.relu);
+        GCN_LAUNCH_CHECK();
+    }
+    return GCN_OK;
+}
+
+template <int VEC, bool DROPOUT>
+static int launch_by_width(const SpmmCall& a) {
+    const int64_t nvec = ceil_div(a.f, VEC);
+    if (nvec <= 1) return launch_variant<1, VEC, 1, DROPOUT>(a);
+    if (nvec <= 2) return launch_variant<2, VEC, 1, DROPOUT>(a);
+    if (nvec <= 4) return launch_variant<4, VEC, 1, DROPOUT>(a);
+    if (nvec <= 8) return launch_variant<8, VEC, 1, DROPOUT>(a);
+    if (nvec <= 16) return launch_variant<16, VEC, 1, DROPOUT>(a);
+    if (nvec <= 32) return launch_variant<32, VEC, 1, DROPOUT>(a);
+    if (nvec <= 64) return launch_variant<64, VEC, 1, DROPOUT>(a);
+    return launch_variant<64, VEC, 2, DROPOUT>(a);  // wider rows: passes of 128 vectors
+}
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static inline int64_t partial_ld(int64_t f) { return (f + 3) / 4 * 4; }
+
+template <bool DROPOUT>
+static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
+                      int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
+                      size_t workspace_bytes, DropArgs dr, void* stream) {
+    if (!plan) return fail(GCN_ERR_BAD_ARG, "plan is null");
+    if (f < 0 || ldb < f || ldc < f || ldb > INT32_MAX || f > INT32_MAX - 1024)
+        return fail(GCN_ERR_BAD_ARG, "bad width: f=%lld ldb=%lld ldc=%lld", (long long)f, (long long)ldb, (long long)ldc);
+    if (!indptr || (plan->nnz > 0 && (!indices || !vals))) return fail(GCN_ERR_BAD_ARG, "null CSR pointer");
+    if (plan->n_rows == 0 || f == 0) return GCN_OK;
+    if (!c || (plan->nnz > 0 && !b)) return fail(GCN_ERR_BAD_ARG, "null dense pointer");
+    if (flags & ~GCN_RELU) return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    SpmmCall a;
+    a.plan = plan;
+    a.indptr = indptr;
+    a.indices = indices;
+    a.vals = vals;
+    a.f = f;
+    a.b = b;
+    a.ldb = (uint32_t)ldb;
+    a.c = c;
+    a.ldc = ldc;
+    a.relu = (flags & GCN_RELU) ? 1 : 0;
+    a.part = nullptr;
+    a.ldp = partial_ld(f);
+    a.dr = dr;
+    a.st = (hipStream_t)stream;
+    if (plan->n_chunks > 0) {
+        const size_t need = (size_t)plan->n_chunks * (size_t)a.ldp * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return fail(GCN_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        if (!aligned16(workspace)) return fail(GCN_ERR_BAD_ARG, "workspace must be 16-byte aligned");
+        a.part = (float*)workspace;
+    }
+    const bool vec4 = (f % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(b) && aligned16(c);
+    return vec4 ? launch_by_width<4, DROPOUT>(a) : launch_by_width<1, DROPOUT>(a);
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+extern "C" {
+
+int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, gcn_spmm_plan** plan_out,
+                         void* stream) {
+    if (!plan_out) return fail(GCN_ERR_BAD_ARG, "plan_out is null");
+    *plan_out = nullptr;
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || n_rows > INT32_MAX - 1 || n_cols > INT32_MAX)
+        return fail(GCN_ERR_BAD_ARG, "bad shape %lld x %lld, nnz %lld", (long long)n_rows, (long long)n_cols,
+                    (long long)nnz);
+    if (!indptr) return fail(GCN_ERR_BAD_ARG, "indptr is null");
+    hipStream_t st = (hipStream_t)stream;
+    gcn_spmm_plan* p = new (std::nothrow) gcn_spmm_plan();
+    if (!p) return fail(GCN_ERR_HIP, "out of host memory");
+    p->n_rows = n_rows;
+    p->n_cols = n_cols;
+    p->nnz = nnz;
+    p->n_strips = std::max<int64_t>(1, ceil_div(nnz, kStripNnz));
+    p->n_long = p->n_chunks = 0;
+    p->strip_row = nullptr;
+    p->long_row = nullptr;
+    p->long_chunk = nullptr;
+    p->chunk_long = nullptr;
+    int32_t* d_rows = nullptr;
+    int64_t *d_starts = nullptr, *d_ends = nullptr;
+    unsigned long long* d_count = nullptr;
+    int rc = GCN_OK;
+    auto cleanup_tmp = [&]() {
+        (void)hipFree(d_rows);
+        (void)hipFree(d_starts);
+        (void)hipFree(d_ends);
+        (void)hipFree(d_count);
+    };
+#define PLAN_TRY(expr)                                                                                       \
+    do {                                                                                                     \
+        hipError_t e__ = (expr);                                                                             \
+        if (e__ != hipSuccess) {                                                                             \
+            rc = fail(GCN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            cleanup_tmp();                                                                                   \
+            gcn_spmm_plan_destroy(p);                                                                        \
+            return rc;                                                                                       \
+        }                                                                                                    \
+    } while (0)
+    PLAN_TRY(hipGetDevice(&p->device));
+    PLAN_TRY(hipMalloc(&p->strip_row, (size_t)(p->n_strips + 1) * sizeof(int32_t)));
+    strip_rows_kernel<<<(unsigned)ceil_div(p->n_strips + 1, kBlock), kBlock, 0, st>>>(n_rows, indptr, p->n_strips,
+                                                                                      p->strip_row);
+    PLAN_TRY(hipGetLastError());
+    // rows longer than the split threshold (at most nnz / (kSplitNnz + 1) of them)
+    const int64_t cap = nnz / (kSplitNnz + 1);
+    if (cap > 0 && n_rows > 0) {
+        PLAN_TRY(hipMalloc(&d_rows, (size_t)cap * sizeof(int32_t)));
+        PLAN_TRY(hipMalloc(&d_starts, (size_t)cap * sizeof(int64_t)));
+        PLAN_TRY(hipMalloc(&d_ends, (size_t)cap * sizeof(int64_t)));
+        PLAN_TRY(hipMalloc(&d_count, sizeof(unsigned long long)));
+        PLAN_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
+        collect_long_rows_kernel<<<(unsigned)ceil_div(n_rows, kBlock), kBlock, 0, st>>>(n_rows, indptr, cap, d_rows,
+                                                                                        d_starts, d_ends, d_count);
+        PLAN_TRY(hipGetLastError());
+        unsigned long long count = 0;
+        PLAN_TRY(hipMemcpyAsync(&count, d_count, sizeof(count), hipMemcpyDeviceToHost, st));
+        PLAN_TRY(hipStreamSynchronize(st));
+        if ((int64_t)count > cap) {
+            cleanup_tmp();
+            gcn_spmm_plan_destroy(p);
+            return fail(GCN_ERR_BAD_ARG, "indptr is inconsistent with nnz=%lld", (long long)nnz);
+        }
+        if (count > 0) {
+            std::vector<int32_t> rows(count);
+            std::vector<int64_t> starts(count), ends(count);
+            PLAN_TRY(hipMemcpy(rows.data(), d_rows, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+            PLAN_TRY(hipMemcpy(starts.data(), d_starts, count * sizeof(int64_t), hipMemcpyDeviceToHost));
+            PLAN_TRY(hipMemcpy(ends.data(), d_ends, count * sizeof(int64_t), hipMemcpyDeviceToHost));
+            std::vector<int64_t> order(count);
+            for (size_t i = 0; i < count; ++i) order[i] = (int64_t)i;
+            std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return rows[x] < rows[y]; });
+            std::vector<int32_t> long_row(count);
+            std::vector<int64_t> long_chunk(count + 1);
+            std::vector<int32_t> chunk_long;
+            int64_t total = 0;
+            for (size_t i = 0; i < count; ++i) {
+                const int64_t o = order[i];
+                long_row[i] = rows[o];
+                long_chunk[i] = total;
+                const int64_t nch = ceil_div(ends[o] - starts[o], kSplitNnz);
+                for (int64_t j = 0; j < nch; ++j) chunk_long.push_back((int32_t)i);
+                total += nch;
+            }
+            long_chunk[count] = total;
+            p->n_long = (int64_t)count;
+            p->n_chunks = total;
+            PLAN_TRY(hipMalloc(&p->long_row, count * sizeof(int32_t)));
+            PLAN_TRY(hipMalloc(&p->long_chunk, (count + 1) * sizeof(int64_t)));
+            PLAN_TRY(hipMalloc(&p->chunk_long, (size_t)total * sizeof(int32_t)));
+            PLAN_TRY(hipMemcpy(p->long_row, long_row.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
+            PLAN_TRY(hipMemcpy(p->long_chunk, long_chunk.data(), (count + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+            PLAN_TRY(hipMemcpy(p->chunk_long, chunk_long.data(), (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
+    PLAN_TRY(hipStreamSynchronize(st));
+#undef PLAN_TRY
+    cleanup_tmp();
+    *plan_out = p;
+    return GCN_OK;
+}
+
+int gcn_spmm_plan_destroy(gcn_spmm_plan* plan) {
+    if (!plan) return GCN_OK;
+    (void)hipFree(plan->strip_row);
+    (void)hipFree(plan->long_row);
+    (void)hipFree(plan->long_chunk);
+    (void)hipFree(plan->chunk_long);
+    delete plan;
+    return GCN_OK;
+}
+
+int gcn_spmm_plan_info(const gcn_spmm_plan* plan, int64_t* what4) {
+    if (!plan || !what4) return fail(GCN_ERR_BAD_ARG, "null argument");
+    what4[0] = plan->n_strips;
+    what4[1] = plan->n_long;
+    what4[2] = plan->n_chunks;
+    what4[3] = kSplitNnz;
+    return GCN_OK;
+}
+
+int gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan* plan, int64_t f, size_t* workspace_bytes) {
+    if (!plan || !workspace_bytes || f < 0) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    *workspace_bytes = (size_t)plan->n_chunks * (size_t)partial_ld(f) * sizeof(float);
+    return GCN_OK;
+}
+
+int gcn_spmm_csr_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
+                     int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    DropArgs dr = {nullptr, 0, 1.0f, 1.0f};
+    return spmm_entry<false>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
+                             stream);
+}
+
+int gcn_spmm_csr_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                             const float* vals, const int64_t* perm, int64_t f, const float* b, int64_t ldb, float* c,
+                             int64_t ldc, int flags, float keep_prob, uint64_t seed, uint64_t stream_id,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
+    DropArgs dr = {perm, stream_key(seed, stream_id), keep_prob, 1.0f / keep_prob};
+    return spmm_entry<true>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
+                            stream);
+}
+
+}  // extern "C"

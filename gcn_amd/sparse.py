@@ -1,0 +1,308 @@
+"""Device-resident CSR matrices and the HIP operators on them.
+
+torch is used for device memory and streams only; every computation is a call
+into ``libgcn_hip.so`` through ``gcn_amd._lib``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise ValueError('gcn_amd operators take tensors that live on the GPU')
+
+
+def _workspace(nbytes, device):
+    # torch's caching allocator hands out 512-byte aligned blocks
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _rowmajor(x):
+    """float32 row-major 2-D view (copy only if the layout forces one)."""
+    if x.dim() != 2:
+        raise ValueError('expected a 2-D tensor')
+    if x.dtype != torch.float32:
+        x = x.float()
+    if x.shape[1] > 0 and x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) < x.shape[1]):
+        x = x.contiguous()
+    return x
+
+
+def _ld(x):
+    return x.stride(0) if x.shape[0] > 1 else max(x.shape[1], 1)
+
+
+class SpmmPlan(object):
+    """Owner of a ``gcn_spmm_plan`` (row-length analysis of one CSR structure)."""
+
+    def __init__(self, n_rows, n_cols, nnz, indptr):
+        _require_cuda(indptr)
+        handle = ctypes.c_void_p()
+        _lib.call('gcn_spmm_plan_create', n_rows, n_cols, nnz, _p(indptr), ctypes.byref(handle), _stream())
+        self.handle = handle
+        info = (ctypes.c_int64 * 4)()
+        _lib.call('gcn_spmm_plan_info', self.handle, info)
+        self.n_strips, self.n_long_rows, self.n_chunks, self.split_nnz = (int(v) for v in info)
+        self._ws = {}
+
+    def workspace(self, f, device):
+        nbytes = ctypes.c_size_t()
+        _lib.call('gcn_spmm_plan_workspace_bytes', self.handle, f, ctypes.byref(nbytes))
+        if nbytes.value == 0:
+            return None, 0
+        ws = self._ws.get(nbytes.value)
+        if ws is None:
+            ws = _workspace(nbytes.value, device)
+            self._ws = {nbytes.value: ws}      # keep only the latest size
+        return ws, nbytes.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().gcn_spmm_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class DeviceCSR(object):
+    """CSR matrix in HBM: ``indptr`` int64 [n_rows+1], ``indices`` int32,
+    ``values`` float32.  ``values64`` keeps the float64 values when the matrix
+    came out of ``preprocess_adj``; ``perm`` maps every entry to its position in
+    the matrix this one was transposed from."""
+
+    def __init__(self, n_rows, n_cols, indptr, indices, values, values64=None, perm=None):
+        _require_cuda(indptr, indices, values)
+        if indptr.dtype != torch.int64 or indices.dtype != torch.int32 or values.dtype != torch.float32:
+            raise ValueError('DeviceCSR wants int64 indptr, int32 indices, float32 values')
+        if indptr.numel() != n_rows + 1 or indices.numel() != values.numel():
+            raise ValueError('CSR arrays do not match the shape')
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.indptr, self.indices, self.values = indptr.contiguous(), indices.contiguous(), values.contiguous()
+        self.values64 = values64
+        self.perm = perm
+        self._plan = None
+        self._t = None
+
+    @property
+    def nnz(self):
+        return int(self.indices.numel())
+
+    @property
+    def shape(self):
+        return (self.n_rows, self.n_cols)
+
+    @property
+    def device(self):
+        return self.indptr.device
+
+    @property
+    def plan(self):
+        if self._plan is None:
+            self._plan = SpmmPlan(self.n_rows, self.n_cols, self.nnz, self.indptr)
+        return self._plan
+
+    def check_indices(self):
+        """Raise ValueError if a column index is out of range (the check the
+        reference's TensorFlow kernel makes per nonzero)."""
+        _lib.call('gcn_check_indices', self.nnz, _p(self.indices), self.n_cols, _stream())
+
+    def transpose(self):
+        """Stable transpose (cached): the adjoint operand of the backward products."""
+        if self._t is None:
+            self._t = csr_transpose(self)
+        return self._t
+
+    @classmethod
+    def from_scipy(cls, m, device='cuda'):
+        m = m.tocsr()
+        return cls(m.shape[0], m.shape[1],
+                   torch.as_tensor(m.indptr, dtype=torch.int64).to(device),
+                   torch.as_tensor(m.indices, dtype=torch.int32).to(device),
+                   torch.as_tensor(m.data, dtype=torch.float32).to(device))
+
+
+# --------------------------------------------------------------------------- #
+# graph preprocessing
+# --------------------------------------------------------------------------- #
+def coo_to_csr(n_rows, n_cols, rows, cols, vals=None, add_self_loops=False, binary=False):
+    """COO (any order) -> (indptr int64, indices int32, values float64 or None).
+    Duplicates are summed; ``add_self_loops`` merges in ``sp.eye(n)``."""
+    _require_cuda(rows, cols, vals)
+    rows = rows.to(torch.int32).contiguous()
+    cols = cols.to(torch.int32).contiguous()
+    if vals is not None:
+        vals = vals.to(torch.float64).contiguous()
+    nnz_in = rows.numel()
+    dev = rows.device
+    flags = (_lib.GCN_ADD_SELF_LOOPS if add_self_loops else 0) | (_lib.GCN_BINARY if binary else 0)
+    cap, ws_bytes = ctypes.c_int64(), ctypes.c_size_t()
+    _lib.call('gcn_coo_to_csr_bound', n_rows, nnz_in, flags, ctypes.byref(cap), ctypes.byref(ws_bytes))
+    indptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+    indices = torch.empty(cap.value, dtype=torch.int32, device=dev)
+    vals_out = None if binary else torch.empty(cap.value, dtype=torch.float64, device=dev)
+    nnz_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = _workspace(ws_bytes.value, dev)
+    _lib.call('gcn_coo_to_csr', n_rows, n_cols, nnz_in, _p(rows), _p(cols), _p(vals), flags, _p(indptr), _p(indices),
+              _p(vals_out), _p(nnz_out), _p(ws), ws.numel(), _stream())
+    nnz = int(nnz_out.item())
+    return indptr, indices[:nnz].clone(), (None if binary else vals_out[:nnz].clone())
+
+
+def rows_to_indptr(n_rows, rows):
+    """indptr of a row-grouped triple (rows non-decreasing), order inside rows kept."""
+    _require_cuda(rows)
+    rows = rows.to(torch.int32).contiguous()
+    if rows.numel() > 1 and bool((rows[1:] < rows[:-1]).any()):
+        raise ValueError('rows must be non-decreasing')
+    indptr = torch.empty(n_rows + 1, dtype=torch.int64, device=rows.device)
+    _lib.call('gcn_rows_to_indptr', n_rows, rows.numel(), _p(rows), _p(indptr), _stream())
+    return indptr
+
+
+def row_sums(indptr, vals=None):
+    n = indptr.numel() - 1
+    out = torch.empty(n, dtype=torch.float64, device=indptr.device)
+    _lib.call('gcn_row_sums', n, _p(indptr), _p(vals), _p(out), _stream())
+    return out
+
+
+def degree_scale(rowsum, type='sym'):
+    out = torch.empty_like(rowsum)
+    _lib.call('gcn_degree_scale', rowsum.numel(), _p(rowsum), _norm_code(type), _p(out), _stream())
+    return out
+
+
+def _norm_code(type):
+    if type == 'sym':
+        return _lib.GCN_NORM_SYM
+    if type == 'rw':
+        return _lib.GCN_NORM_RW
+    raise ValueError('Invalid normalisation type: ' + str(type))
+
+
+def normalize_values(indptr, indices, vals, d, type='sym'):
+    """float64 and float32 values of normalize_adj on CSR storage (see gcn_hip.h)."""
+    n = indptr.numel() - 1
+    nnz = indices.numel()
+    out64 = torch.empty(nnz, dtype=torch.float64, device=indptr.device)
+    out32 = torch.empty(nnz, dtype=torch.float32, device=indptr.device)
+    _lib.call('gcn_normalize_adj', n, nnz, _p(indptr), _p(indices), _p(vals), _p(d), _norm_code(type), _p(out64),
+              _p(out32), _stream())
+    return out64, out32
+
+
+def csr_transpose(a):
+    """Stable transpose of a DeviceCSR; ``.perm`` of the result gives source positions."""
+    dev = a.device
+    nnz = a.nnz
+    ws_bytes = ctypes.c_size_t()
+    _lib.call('gcn_csr_transpose_bound', a.n_rows, a.n_cols, nnz, ctypes.byref(ws_bytes))
+    ws = _workspace(ws_bytes.value, dev)
+    t_indptr = torch.empty(a.n_cols + 1, dtype=torch.int64, device=dev)
+    t_indices = torch.empty(nnz, dtype=torch.int32, device=dev)
+    t_vals = torch.empty(nnz, dtype=torch.float32, device=dev)
+    perm = torch.empty(nnz, dtype=torch.int64, device=dev)
+    _lib.call('gcn_csr_transpose', a.n_rows, a.n_cols, nnz, _p(a.indptr), _p(a.indices), _p(a.values), 4,
+              _p(t_indptr), _p(t_indices), _p(t_vals), _p(perm), _p(ws), ws.numel(), _stream())
+    if a.perm is not None:
+        perm = a.perm[perm]
+    return DeviceCSR(a.n_cols, a.n_rows, t_indptr, t_indices, t_vals, perm=perm)
+
+
+# --------------------------------------------------------------------------- #
+# synthetic inputs
+# --------------------------------------------------------------------------- #
+def rmat_csr(scale, edge_factor=16, seed=42, device='cuda'):
+    """CSR structure (indptr int64, indices int32) of the symmetrised, deduplicated R-MAT graph."""
+    cap, ws_bytes = ctypes.c_int64(), ctypes.c_size_t()
+    _lib.call('gcn_rmat_csr_bound', scale, edge_factor, ctypes.byref(cap), ctypes.byref(ws_bytes))
+    n = 1 << scale
+    indptr = torch.empty(n + 1, dtype=torch.int64, device=device)
+    indices = torch.empty(cap.value, dtype=torch.int32, device=device)
+    nnz_out = torch.zeros(1, dtype=torch.int64, device=device)
+    ws = _workspace(ws_bytes.value, indptr.device)
+    _lib.call('gcn_rmat_csr', scale, edge_factor, seed, _p(indptr), _p(indices), _p(nnz_out), _p(ws), ws.numel(),
+              _stream())
+    nnz = int(nnz_out.item())
+    del ws
+    return indptr, indices[:nnz].clone()
+
+
+def synthetic_dense(n, f, seed=7, device='cuda'):
+    out = torch.empty((n, f), dtype=torch.float32, device=device)
+    _lib.call('gcn_fill_synthetic_f32', n * f, seed, _p(out), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# products
+# --------------------------------------------------------------------------- #
+def spmm(a, b, relu=False, out=None):
+    """``a @ b`` for a DeviceCSR ``a`` and dense float32 ``b`` (optionally with ReLU fused)."""
+    _require_cuda(b)
+    b = _rowmajor(b)
+    if b.shape[0] != a.n_cols:
+        raise ValueError('shape mismatch: %s @ %s' % (a.shape, tuple(b.shape)))
+    f = b.shape[1]
+    if out is None:
+        out = torch.empty((a.n_rows, f), dtype=torch.float32, device=b.device)
+    ws, ws_bytes = a.plan.workspace(f, b.device)
+    _lib.call('gcn_spmm_csr_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(b), _ld(b),
+              _p(out), _ld(out), _lib.GCN_RELU if relu else 0, _p(ws), ws_bytes, _stream())
+    return out
+
+
+def spmm_dropout(a, b, keep_prob, seed, stream_id, relu=False, out=None):
+    """``sparse_dropout(a, keep_prob) @ b`` with the dropout fused into the product.
+    Entry ids for the random stream come from ``a.perm`` when ``a`` is a transposed copy."""
+    _require_cuda(b)
+    b = _rowmajor(b)
+    if b.shape[0] != a.n_cols:
+        raise ValueError('shape mismatch: %s @ %s' % (a.shape, tuple(b.shape)))
+    f = b.shape[1]
+    if out is None:
+        out = torch.empty((a.n_rows, f), dtype=torch.float32, device=b.device)
+    ws, ws_bytes = a.plan.workspace(f, b.device)
+    _lib.call('gcn_spmm_csr_dropout_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), _p(a.perm), f,
+              _p(b), _ld(b), _p(out), _ld(out), _lib.GCN_RELU if relu else 0, float(keep_prob), int(seed),
+              int(stream_id), _p(ws), ws_bytes, _stream())
+    return out
+
+
+def dropout(x, keep_prob, seed, stream_id, gate=None):
+    """tf.nn.dropout(x, keep_prob); with ``gate`` the result is also zeroed where gate <= 0."""
+    _require_cuda(x, gate)
+    x = _rowmajor(x)
+    if gate is not None:
+        gate = _rowmajor(gate)
+    y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.call('gcn_dropout_f32', x.shape[0], x.shape[1], _p(x), _ld(x), _p(gate), 0 if gate is None else _ld(gate),
+              _p(y), _ld(y), float(keep_prob), int(seed), int(stream_id), _stream())
+    return y
+
+
+def gemm(a, b, trans_b=False, relu=False):
+    """``a @ b`` (or ``a @ b.T``) in float32 on the MFMA pipe."""
+    _require_cuda(a, b)
+    a, b = _rowmajor(a), _rowmajor(b)
+    m, k = a.shape
+    n = b.shape[0] if trans_b else b.shape[1]
+    if (b.shape[1] if trans_b else b.shape[0]) != k:
+        raise ValueError('shape mismatch in gemm')
+    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    _lib.call('gcn_gemm_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), 1 if trans_b else 0, _p(c), _ld(c),
+              _lib.GCN_RELU if relu else 0, _stream())
+    return c

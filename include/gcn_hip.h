@@ -1,0 +1,174 @@
+/* gcn_hip.h -- C ABI of libgcn_hip.so: the GCN propagation path A_hat . (X . W)
+ * as HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (hareeshks/gcn) has no native interface: its path is Python
+ * calling TensorFlow / scipy.  Each entry point below names the reference call
+ * site(s) whose arithmetic it replaces; the Python package gcn_amd binds them
+ * with ctypes under the reference's own function names.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says "host";
+ *  - the caller owns every buffer; the library allocates only inside
+ *    gcn_spmm_plan_create (plan metadata, freed by gcn_spmm_plan_destroy);
+ *  - `stream` is a hipStream_t passed as void*; every launch is asynchronous
+ *    on it; only the functions marked [sync] wait for the stream;
+ *  - CSR: indptr int64 [n_rows+1], indices int32, values float32 (float64 where
+ *    stated); dense matrices are row-major float32 with a leading dimension in
+ *    elements;
+ *  - every function returns a gcn_status; gcn_last_error_string() describes the
+ *    last failure on the calling thread.  No C++ exception crosses this ABI.
+ */
+#ifndef GCN_HIP_H_
+#define GCN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GCN_OK = 0,
+    GCN_ERR_BAD_ARG = 1,      /* Python: ValueError   (reference: ValueError at train.py:141, utils.py:293) */
+    GCN_ERR_INDEX_RANGE = 2,  /* Python: ValueError   (TensorFlow: InvalidArgumentError for out-of-range sparse indices) */
+    GCN_ERR_HIP = 3,          /* Python: RuntimeError */
+    GCN_ERR_WORKSPACE = 4     /* Python: ValueError   (workspace too small) */
+} gcn_status;
+
+/* flags of gcn_coo_to_csr */
+#define GCN_ADD_SELF_LOOPS 1  /* adj + sp.eye(n): ADD 1.0 on the diagonal            (gcn/utils.py:321) */
+#define GCN_BINARY 2          /* duplicates collapse to one entry of value 1 (simple graph, no values out) */
+/* flags of the SpMM / GEMM entry points */
+#define GCN_RELU 1            /* act = relu fused into the epilogue                  (gcn/layers.py:214, models.py:17) */
+/* type of gcn_normalize_adj */
+#define GCN_NORM_SYM 0        /* D^-1/2 A D^-1/2                                     (gcn/utils.py:299-308) */
+#define GCN_NORM_RW 1         /* D^-1 A                                              (gcn/utils.py:309-315) */
+
+int gcn_version(void);
+const char* gcn_last_error_string(void);
+
+/* ------------------------------------------------------------------------- *
+ * Graph preprocessing -- integer work, bit-exact.                            *
+ * ------------------------------------------------------------------------- */
+
+/* Capacity and scratch needed by gcn_coo_to_csr.  Host outputs. */
+int gcn_coo_to_csr_bound(int64_t n_rows, int64_t nnz_in, int flags, int64_t* nnz_capacity, size_t* workspace_bytes);
+
+/* COO (any order, duplicates allowed) -> CSR with ascending columns and
+ * duplicates summed; with GCN_ADD_SELF_LOOPS one extra (i,i,1.0) per row is
+ * merged in.  Replaces the scipy conversions behind `adj + sp.eye(adj.shape[0])`
+ * and `sp.coo_matrix(adj)` at gcn/utils.py:300,321.
+ * vals may be NULL (all ones).  vals_out (float64) may be NULL with GCN_BINARY.
+ * indices_out / vals_out must hold nnz_capacity entries; *nnz_out (device
+ * int64) receives the merged count. */
+int gcn_coo_to_csr(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const int32_t* rows, const int32_t* cols,
+                   const double* vals, int flags, int64_t* indptr_out, int32_t* indices_out, double* vals_out,
+                   int64_t* nnz_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* indptr from a non-decreasing row array: CSR view of a row-grouped triple
+ * that keeps the triple's own order inside every row (the feature triple of
+ * sparse_to_tuple, gcn/utils.py:258-275 as fed at train.py:118). */
+int gcn_rows_to_indptr(int64_t n_rows, int64_t nnz, const int32_t* rows, int64_t* indptr_out, void* stream);
+
+/* rowsum = adj.sum(1) (gcn/utils.py:301, 310).  vals NULL = all ones. float64 out. */
+int gcn_row_sums(int64_t n_rows, const int64_t* indptr, const double* vals, double* rowsum_out, void* stream);
+
+/* d = rowsum^-0.5 (GCN_NORM_SYM, gcn/utils.py:305-306) or rowsum^-1
+ * (GCN_NORM_RW, utils.py:311-312), float64, inf -> 0. */
+int gcn_degree_scale(int64_t n_rows, const double* rowsum, int type, double* d_out, void* stream);
+
+/* normalize_adj (gcn/utils.py:297-315) on CSR storage, d from gcn_degree_scale.
+ * For entry k stored at (r, c):  SYM: w[k] = (vals[k] * d[c]) * d[r], which is
+ * the value of result[c, r] -- the element order of the triple the reference
+ * returns (column-major); for a symmetric adj it is also the CSR of the result.
+ * RW: w[k] = d[r] * vals[k].  float64 arithmetic; vals NULL = all ones;
+ * vals64_out and/or vals32_out (the float32 cast made by the float32
+ * placeholder at train.py:145) may be NULL. */
+int gcn_normalize_adj(int64_t n_rows, int64_t nnz, const int64_t* indptr, const int32_t* indices, const double* vals,
+                      const double* d, int type, double* vals64_out, float* vals32_out, void* stream);
+
+int gcn_csr_transpose_bound(int64_t n_rows, int64_t n_cols, int64_t nnz, size_t* workspace_bytes);
+
+/* Stable CSR transpose (source rows ascend inside every output row): the
+ * adjoint operand of the backward products A_hat^T.dZ and X'^T.dP that
+ * `minimize` builds at gcn/models.py:86.  vals: val_bytes 0 (none), 4 or 8.
+ * perm_out (int64, may be NULL): source position of every output entry. */
+int gcn_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                      const void* vals, int val_bytes, int64_t* t_indptr, int32_t* t_indices, void* t_vals,
+                      int64_t* perm_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Range check of CSR column indices: GCN_ERR_INDEX_RANGE if any is outside
+ * [0, n_cols) -- the check TensorFlow's kernel makes per nonzero.  [sync] */
+int gcn_check_indices(int64_t nnz, const int32_t* indices, int64_t n_cols, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Synthetic inputs for measurement (the reference has no generator).         *
+ * ------------------------------------------------------------------------- */
+
+int gcn_rmat_csr_bound(int scale, int edge_factor, int64_t* nnz_capacity, size_t* workspace_bytes);
+
+/* R-MAT (a,b,c,d)=(0.57,0.19,0.19,0.05), edge_factor*2^scale generated pairs,
+ * self-loops dropped, symmetrised, deduplicated -> CSR structure of a simple
+ * undirected graph (the kind nx.from_dict_of_lists builds at gcn/utils.py:123).
+ * Integer-only, counter-based: identical to the CPU oracle bit for bit. */
+int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int64_t* indptr_out, int32_t* indices_out,
+                 int64_t* nnz_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[i] = (int32(h >> 32) >> 8) * 2^-23 in [-1,1), h = splitmix(key(seed) ^ i). */
+int gcn_fill_synthetic_f32(int64_t count, uint64_t seed, float* out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Sparse x dense products -- the hot path.                                   *
+ * ------------------------------------------------------------------------- */
+
+typedef struct gcn_spmm_plan gcn_spmm_plan;
+
+/* Row-length analysis of one CSR structure: nnz-balanced strips for ordinary
+ * rows, chunk table for rows longer than the split threshold.  [sync] */
+int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, gcn_spmm_plan** plan_out,
+                         void* stream);
+int gcn_spmm_plan_destroy(gcn_spmm_plan* plan);
+/* host-side facts about a plan: what[0]=n_strips, [1]=n_long_rows, [2]=n_chunks, [3]=split threshold */
+int gcn_spmm_plan_info(const gcn_spmm_plan* plan, int64_t* what4);
+int gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan* plan, int64_t f, size_t* workspace_bytes);
+
+/* C[n_rows x f] = A . B, A in CSR, B [n_cols x f]: `dot(x, y, sparse=True)`
+ * = tf.sparse_tensor_dense_matmul at gcn/layers.py:28-31, called at
+ * layers.py:202 (A_hat . (XW)) and layers.py:198-199 (X . W0).  Every output row
+ * of at most `split threshold` nonzeros is accumulated sequentially in storage
+ * order with a separate float32 multiply and add (the order of the serial
+ * CPU loop); longer rows are summed in fixed-size chunks, then chunk by chunk. */
+int gcn_spmm_csr_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
+                     int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* Same product with sparse_dropout (gcn/layers.py:19-25) fused on A's entries:
+ * entry k is kept iff floor(keep_prob + u_k) == 1 in float32 and then scaled by
+ * float32(1/keep_prob); u_k is the counter-based uniform of entry id
+ * (perm ? perm[k] : k) in stream (seed, stream_id).  perm lets a transposed
+ * copy of X reproduce the mask of the original feed order. */
+int gcn_spmm_csr_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                             const float* vals, const int64_t* perm, int64_t f, const float* b, int64_t ldb, float* c,
+                             int64_t ldc, int flags, float keep_prob, uint64_t seed, uint64_t stream_id,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Dense pieces of the layer.                                                 *
+ * ------------------------------------------------------------------------- */
+
+/* y = (x / keep_prob) * floor(keep_prob + u): tf.nn.dropout at gcn/layers.py:185.
+ * gate (may be NULL): additionally y = 0 where gate <= 0 (ReLU backward). */
+int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, const float* gate, int64_t ldg, float* y,
+                    int64_t ldy, float keep_prob, uint64_t seed, uint64_t stream_id, void* stream);
+
+/* C[m x n] = A . op(B) in float32 on the f32 MFMA pipe: tf.matmul at
+ * gcn/layers.py:32-33 (H . W).  A is [m x k]; trans_b = 0: B is [k x n];
+ * trans_b = 1: B is stored [n x k] (dH = dP . W^T in the backward pass). */
+int gcn_gemm_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                 int trans_b, float* c, int64_t ldc, int flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCN_HIP_H_ */

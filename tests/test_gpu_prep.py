@@ -1,0 +1,168 @@
+"""GPU parity: graph preprocessing kernels against the golden vectors made by the
+reference's own gcn/utils.py (preprocess_adj, utils.py:318-323) and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dtype=None):
+    import torch
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def test_coo_to_csr_with_self_loops_matches_reference(graph_fx):
+    import torch
+    from gcn_amd import sparse
+    name, fx = graph_fx
+    n = int(fx['n'])
+    rng = np.random.RandomState(0)
+    order = rng.permutation(fx['adj_row'].size)          # the kernel must not depend on input order
+    rows, cols = _t(fx['adj_row'][order]), _t(fx['adj_col'][order])
+    indptr, indices, vals = sparse.coo_to_csr(n, n, rows, cols, add_self_loops=True)
+    assert np.array_equal(indptr.cpu().numpy(), fx['ai_indptr'].astype(np.int64))
+    assert np.array_equal(indices.cpu().numpy(), fx['ai_indices'])
+    assert np.array_equal(vals.cpu().numpy(), fx['ai_data'])            # diagonal 2.0 where A had a self-loop
+    deg = sparse.row_sums(indptr, vals)
+    assert np.array_equal(deg.cpu().numpy(), fx['deg'])
+    # binary structure-only variant
+    indptr_b, indices_b, none = sparse.coo_to_csr(n, n, rows, cols, add_self_loops=True, binary=True)
+    assert none is None
+    assert torch.equal(indptr_b, indptr) and torch.equal(indices_b, indices)
+
+
+def test_normalize_adj_bit_exact(graph_fx):
+    from gcn_amd import sparse
+    name, fx = graph_fx
+    n = int(fx['n'])
+    indptr, indices, vals = sparse.coo_to_csr(n, n, _t(fx['adj_row']), _t(fx['adj_col']), add_self_loops=True)
+    deg = sparse.row_sums(indptr, vals)
+    d = sparse.degree_scale(deg, 'sym')
+    with np.errstate(divide='ignore'):
+        d_ref = np.power(fx['deg'], -0.5)
+    assert np.array_equal(d.cpu().numpy(), d_ref)
+    v64, v32 = sparse.normalize_values(indptr, indices, vals, d, 'sym')
+    # the triple of the reference is column-major: entry k of the CSR of (A+I) is result[col, row]
+    rows = np.repeat(np.arange(n), np.diff(fx['ai_indptr']))
+    assert np.array_equal(np.stack([fx['ai_indices'], rows], 1), fx['hat_indices'])
+    assert np.array_equal(v64.cpu().numpy(), fx['hat_values'])
+    assert np.array_equal(v32.cpu().numpy(), fx['hat_values'].astype(np.float32))
+
+
+def test_degree_scale_against_numpy_pow():
+    """x^-0.5 in float64 for every integer degree up to 2^20 and a band of huge ones."""
+    from gcn_amd import sparse
+    x = np.concatenate([np.arange(0, 1 << 20, dtype=np.float64),
+                        np.arange(1 << 30, (1 << 30) + 4096, dtype=np.float64),
+                        np.array([0.25, 0.5, 1.5, 2.5, 1e-300, 1e300])])
+    d = sparse.degree_scale(_t(x), 'sym').cpu().numpy()
+    with np.errstate(divide='ignore'):
+        ref = np.power(x, -0.5)
+    ref[np.isinf(ref)] = 0.0
+    bad = np.flatnonzero(d != ref)
+    assert bad.size == 0, (bad[:10], d[bad[:10]], ref[bad[:10]])
+    dinv = sparse.degree_scale(_t(x), 'rw').cpu().numpy()
+    with np.errstate(divide='ignore'):
+        ref = np.power(x, -1.0)
+    ref[np.isinf(ref)] = 0.0
+    assert np.array_equal(dinv, ref)
+
+
+def test_coo_to_csr_sums_duplicates_and_handles_empty_rows(oracle):
+    from gcn_amd import sparse
+    rng = np.random.RandomState(1)
+    n_rows, n_cols = 1000, 700
+    rows = rng.randint(0, n_rows, 20000)
+    rows[rows % 7 == 0] = 3                       # many empty rows, one crowded row
+    cols = rng.randint(0, 50, 20000)              # plenty of duplicates
+    vals = rng.randint(1, 5, 20000).astype(np.float64)
+    ip, ix, v = sparse.coo_to_csr(n_rows, n_cols, _t(rows), _t(cols), _t(vals))
+    rip, rix, rv = oracle.coo_to_csr_sum(n_rows, n_cols, rows, cols, vals)
+    assert np.array_equal(ip.cpu().numpy(), rip)
+    assert np.array_equal(ix.cpu().numpy(), rix)
+    assert np.array_equal(v.cpu().numpy(), rv)
+    # no values given: duplicates count
+    ip2, ix2, v2 = sparse.coo_to_csr(n_rows, n_cols, _t(rows), _t(cols))
+    _, _, rv2 = oracle.coo_to_csr_sum(n_rows, n_cols, rows, cols, np.ones(rows.size))
+    assert np.array_equal(v2.cpu().numpy(), rv2)
+    # empty input
+    import torch
+    e = torch.empty(0, dtype=torch.int32, device='cuda')
+    ip3, ix3, v3 = sparse.coo_to_csr(5, 5, e, e)
+    assert ip3.cpu().tolist() == [0] * 6 and ix3.numel() == 0
+    ip4, ix4, v4 = sparse.coo_to_csr(5, 5, e, e, add_self_loops=True)
+    assert ip4.cpu().tolist() == [0, 1, 2, 3, 4, 5] and ix4.cpu().tolist() == [0, 1, 2, 3, 4]
+
+
+def test_rows_to_indptr_and_transpose(dataset_fx, oracle):
+    import torch
+    from gcn_amd import sparse
+    name, fx = dataset_fx
+    n, f_in = (int(v) for v in fx['feat_shape'])
+    coords = fx['feat_coords']
+    indptr = sparse.rows_to_indptr(n, _t(coords[:, 0]))
+    assert np.array_equal(indptr.cpu().numpy(), fx['feat_indptr'].astype(np.int64))
+    x = sparse.DeviceCSR(n, f_in, indptr, _t(coords[:, 1]), _t(fx['feat_values'], torch.float32))
+    xt = x.transpose()
+    tp, ti, tv, perm = oracle.csr_transpose(n, f_in, fx['feat_indptr'], coords[:, 1],
+                                            fx['feat_values'].astype(np.float32))
+    assert np.array_equal(xt.indptr.cpu().numpy(), tp)
+    assert np.array_equal(xt.indices.cpu().numpy(), ti)
+    assert np.array_equal(xt.values.cpu().numpy(), tv)
+    assert np.array_equal(xt.perm.cpu().numpy(), perm)
+    with pytest.raises(ValueError):
+        sparse.rows_to_indptr(n, _t(coords[::-1, 0].copy()))
+
+
+def test_hat_is_symmetric_so_transpose_is_identity(graph_fx):
+    import torch
+    from gcn_amd import sparse
+    name, fx = graph_fx
+    n = int(fx['n'])
+    a = sparse.DeviceCSR(n, n, _t(fx['ai_indptr'], torch.int64), _t(fx['ai_indices']),
+                         _t(fx['hat_values'], torch.float32))
+    at = a.transpose()
+    assert torch.equal(at.indptr, a.indptr) and torch.equal(at.indices, a.indices)
+    assert torch.equal(at.values, a.values)
+
+
+def test_check_indices_raises_like_the_reference_kernel():
+    import torch
+    from gcn_amd import sparse
+    indptr = torch.tensor([0, 2, 3], dtype=torch.int64, device='cuda')
+    good = sparse.DeviceCSR(2, 3, indptr, torch.tensor([0, 2, 1], dtype=torch.int32, device='cuda'),
+                            torch.ones(3, device='cuda'))
+    good.check_indices()
+    bad = sparse.DeviceCSR(2, 3, indptr, torch.tensor([0, 3, 1], dtype=torch.int32, device='cuda'),
+                           torch.ones(3, device='cuda'))
+    with pytest.raises(ValueError):
+        bad.check_indices()
+
+
+@pytest.mark.parametrize('scale,edge_factor', [(8, 16), (12, 16), (14, 4)])
+def test_rmat_matches_oracle_bit_for_bit(oracle, scale, edge_factor):
+    from gcn_amd import sparse
+    indptr, indices = sparse.rmat_csr(scale, edge_factor, seed=42)
+    rip, rix = oracle.rmat_csr(scale, edge_factor, seed=42)
+    assert np.array_equal(indptr.cpu().numpy(), rip)
+    assert np.array_equal(indices.cpu().numpy(), rix)
+    # simple undirected graph: no self-loops, symmetric, strictly ascending columns
+    ip, ix = indptr.cpu().numpy(), indices.cpu().numpy()
+    rows = np.repeat(np.arange(1 << scale), np.diff(ip))
+    assert not np.any(rows == ix)
+    key = rows.astype(np.int64) << 32 | ix
+    assert np.all(np.diff(key) > 0)
+    assert np.array_equal(np.sort(ix.astype(np.int64) << 32 | rows), key)
+
+
+def test_synthetic_dense_matches_oracle(oracle):
+    from gcn_amd import sparse
+    x = sparse.synthetic_dense(1000, 37, seed=7)
+    ref = oracle.synthetic_dense(1000, 37, seed=7)
+    assert np.array_equal(x.cpu().numpy(), ref)
+    assert ref.min() >= -1.0 and ref.max() < 1.0
