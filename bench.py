@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: C = A_hat . B on a synthetic R-MAT graph (the SpMM of gcn/layers.py:202).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the product over the whole graph with inputs resident in HBM.
+Default workload: R-MAT scale 24 (2^24 nodes), edge factor 16 (average degree ~32 after
+symmetrisation), 256-wide float32 features, A_hat = D^-1/2 (A+I) D^-1/2.  With N > 1 the rows
+of A_hat, B and C are split in N contiguous blocks; every step all-gathers B over RCCL and then
+multiplies locally (strong scaling: the graph does not grow with N).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak, GB/s
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--scale', type=int, default=24)
+    ap.add_argument('--edge-factor', type=int, default=16)
+    ap.add_argument('--features', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-row-stride', type=int, default=64,
+                    help='the CPU baseline multiplies every k-th row of the same matrix')
+    return ap.parse_args()
+
+
+def bytes_min(n_rows, n_cols, nnz, f):
+    """Compulsory traffic of one product: (index + value) per nonzero, int64 row pointers,
+    B read once, C written once."""
+    return 8 * nnz + 8 * (n_rows + 1) + 4 * n_cols * f + 4 * n_rows * f
+
+
+def bytes_gather(n_rows, nnz, f):
+    """Upper traffic model: every nonzero fetches its own f-wide row of B."""
+    return 8 * nnz + 8 * (n_rows + 1) + 4 * f * nnz + 4 * n_rows * f
+
+
+def build_graph(scale, edge_factor):
+    from gcn_amd import sparse
+    indptr, indices = sparse.rmat_csr(scale, edge_factor, seed=42, self_loops=True)
+    deg = sparse.row_sums(indptr, None)
+    d = sparse.degree_scale(deg, 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    del deg, d
+    torch.cuda.empty_cache()
+    return indptr, indices, vals
+
+
+def cpu_baseline(a, b_dev, c_dev, row_stride):
+    """Time the CPU oracle (the serial nnz loop of the reference's TensorFlow kernel, restated in C)
+    on every `row_stride`-th row of the same matrix against the same B, and check the GPU rows."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import gcn_oracle as oracle
+    n = a.n_rows
+    rows = torch.arange(0, n, row_stride, device=a.device)
+    starts = a.indptr[rows]
+    lens = a.indptr[rows + 1] - starts
+    sub_indptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=a.device)
+    sub_indptr[1:] = torch.cumsum(lens, 0)
+    nnz_s = int(sub_indptr[-1].item())
+    pos = torch.repeat_interleave(starts - sub_indptr[:-1], lens) + torch.arange(nnz_s, device=a.device)
+    ip = sub_indptr.cpu().numpy()
+    ix = a.indices[pos].cpu().numpy()
+    vv = a.values[pos].cpu().numpy()
+    del pos
+    b = b_dev.cpu().numpy()
+    f = b.shape[1]
+    out = np.empty((rows.numel(), f), dtype=np.float32)
+    t0 = time.perf_counter()
+    oracle.spmm_csr(ip, ix, vv, b, threads=1, out=out)
+    t_serial = time.perf_counter() - t0
+    threads = min(oracle._load_clib().oracle_num_threads(), 16)
+    t0 = time.perf_counter()
+    out_mt = oracle.spmm_csr(ip, ix, vv, b, threads=threads)
+    t_mt = time.perf_counter() - t0
+    gpu_rows = c_dev[rows].cpu().numpy()
+    short = np.diff(ip) <= a.plan.split_nnz
+    exact = bool(np.array_equal(gpu_rows[short], out[short]) and np.array_equal(out, out_mt))
+    scale_ref = float(np.abs(out).max())
+    max_err = float(np.abs(gpu_rows - out).max() / scale_ref)
+    full = bytes_min(n, a.n_cols, a.nnz, f)
+    frac = nnz_s / a.nnz
+    sample = ('every %d-th row of the same A_hat (%d rows, %d nonzeros = %.4f of the matrix) times the '
+              'same B; GB/s = that fraction of the full product\'s algorithmic bytes / time'
+              % (row_stride, rows.numel(), nnz_s, frac))
+    base = {'value': full * frac / t_serial / 1e9, 'unit': 'GB/s', 'cores': 1, 'kind': 'port',
+            'sample': sample, 'seconds': t_serial}
+    allcores = {'value': full * frac / t_mt / 1e9, 'unit': 'GB/s', 'cores': threads, 'kind': 'port',
+                'sample': sample, 'seconds': t_mt}
+    check = {'rows_checked': int(rows.numel()), 'short_rows_bit_exact': exact, 'max_rel_err': max_err}
+    return base, allcores, check
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d does not match WORLD_SIZE %d: launch with torch.distributed.run'
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from gcn_amd import sparse, dist as gdist
+
+    n = 1 << args.scale
+    f = args.features
+    indptr, indices, vals = build_graph(args.scale, args.edge_factor)
+    nnz = int(indices.numel())
+    b_full = sparse.synthetic_dense(n, f, seed=7)
+
+    if world == 1:
+        a = sparse.DeviceCSR(n, n, indptr, indices, vals)
+        c = torch.empty((n, f), dtype=torch.float32, device=dev)
+        a.plan.set_timing(True)
+
+        def step():
+            sparse.spmm(a, b_full, out=c)
+    else:
+        shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, rank, world)
+        del indptr, indices, vals
+        b_local = b_full[shard.row_begin:shard.row_end].clone()
+        del b_full
+        torch.cuda.empty_cache()
+        op = gdist.AllGatherSpmm(shard, f)
+        a = shard.local
+        a.plan.set_timing(True)
+
+        def step():
+            op(b_local)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(a.plan.last_timing())          # waits for this step's kernels (per-step event read)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        total_min = bytes_min(n, n, nnz, f)
+        total_gather = bytes_gather(n, nnz, f)
+        value = total_min / (ms_per_step * 1e-3) / 1e9
+        row_ms = float(np.mean([k[0] for k in kernel_ms]))
+        red_ms = float(np.mean([k[1] for k in kernel_ms]))
+        # the row kernel of THIS rank: its shard of the rows against the whole of B
+        local_min = bytes_min(a.n_rows, a.n_cols, a.nnz, f)
+        achieved = local_min / (row_ms * 1e-3) / 1e9
+        line = {
+            'metric': 'SpMM HBM GB/s', 'value': value, 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'A_hat.B, R-MAT scale %d edge factor %d (+I, sym-normalised), F=%d'
+                                   % (args.scale, args.edge_factor, f),
+                       'n_nodes': n, 'nnz': nnz, 'features': f,
+                       'parallelism': 'rows/%d + all-gather(B)' % world if world > 1 else 'single GPU'},
+            'pct_of_hbm_peak': 100.0 * value / (HBM_PEAK_GBPS * world),
+            'gather_gbps': total_gather / (ms_per_step * 1e-3) / 1e9,
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': 'spmm_rows_kernel', 'kernel_ms': row_ms, 'reduce_kernel_ms': red_ms,
+                         'algorithmic_bytes': local_min},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, allcores, check = cpu_baseline(a, b_full, c, args.cpu_row_stride)
+            line['cpu_baseline'] = base
+            line['cpu_baseline_all_cores'] = allcores
+            line['parity_sample'] = check
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -43,13 +43,15 @@ SIGNATURES = {
     'gcn_csr_transpose_bound': [_i64, _i64, _i64, _psz],
     'gcn_csr_transpose': [_i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'gcn_check_indices': [_i64, _vp, _i64, _vp],
-    'gcn_rmat_csr_bound': [_int, _int, _pi64, _psz],
-    'gcn_rmat_csr': [_int, _int, _u64, _vp, _vp, _vp, _vp, _sz, _vp],
+    'gcn_rmat_csr_bound': [_int, _int, _int, _pi64, _psz],
+    'gcn_rmat_csr': [_int, _int, _u64, _int, _vp, _vp, _vp, _vp, _sz, _vp],
     'gcn_fill_synthetic_f32': [_i64, _u64, _vp, _vp],
     'gcn_spmm_plan_create': [_i64, _i64, _i64, _vp, ctypes.POINTER(_vp), _vp],
     'gcn_spmm_plan_destroy': [_vp],
     'gcn_spmm_plan_info': [_vp, _pi64],
     'gcn_spmm_plan_workspace_bytes': [_vp, _i64, _psz],
+    'gcn_spmm_plan_set_timing': [_vp, _int],
+    'gcn_spmm_plan_last_timing': [_vp, ctypes.POINTER(ctypes.c_float)],
     'gcn_spmm_csr_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _sz, _vp],
     'gcn_spmm_csr_dropout_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64,
                                  _vp, _sz, _vp],

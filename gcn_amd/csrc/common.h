@@ -49,6 +49,19 @@ __device__ __forceinline__ bool keep_entry(uint64_t key, uint64_t idx, float kee
     return floorf(__fadd_rn(keep_prob, uniform24(key, idx))) >= 1.0f;
 }
 
+// Fixed bijection on [0, 2^bits): odd multiplications and xor-shifts, each invertible modulo 2^bits.
+// The R-MAT generator relabels vertices with it so that hub vertices are spread over the id range.
+__host__ __device__ __forceinline__ uint64_t scramble_id(uint64_t v, int bits, uint64_t key) {
+    const uint64_t mask = (bits >= 64) ? ~0ull : ((1ull << bits) - 1);
+    const int sh = (bits + 1) / 2;
+    uint64_t x = (v + key) & mask;
+    x = (x * 0x9E3779B97F4A7C15ull) & mask;
+    x ^= x >> sh;
+    x = (x * 0xBF58476D1CE4E5B9ull) & mask;
+    x ^= x >> sh;
+    return x;
+}
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -313,10 +313,15 @@ __global__ void check_indices_kernel(int64_t nnz, const int32_t* __restrict__ in
 // ------------------------------------------------------------------------------------------------
 // R-MAT and synthetic features
 // ------------------------------------------------------------------------------------------------
-__global__ void rmat_keys_kernel(int scale, int64_t n_pairs, uint64_t key, uint32_t ta, uint32_t tb, uint32_t tc,
-                                 uint64_t* __restrict__ keys) {
+__global__ void rmat_keys_kernel(int scale, int64_t n_pairs, int64_t n_loops, uint64_t key, uint64_t label_key,
+                                 uint32_t ta, uint32_t tb, uint32_t tc, uint64_t* __restrict__ keys) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_pairs) return;
+    if (e >= n_pairs + n_loops) return;
+    if (e >= n_pairs) {  // the diagonal of A + I
+        const uint64_t d = (uint64_t)(e - n_pairs);
+        keys[2 * n_pairs + d] = (d << 32) | d;
+        return;
+    }
     uint64_t u = 0, v = 0;
     for (int level = 0; level < scale; ++level) {
         const uint32_t r = (uint32_t)(sm64(key ^ ((uint64_t)e * (uint64_t)scale + (uint64_t)level)) >> 32);
@@ -325,6 +330,8 @@ __global__ void rmat_keys_kernel(int scale, int64_t n_pairs, uint64_t key, uint3
         v = (v << 1) | (q & 1);
     }
     const bool loop = (u == v);
+    u = scramble_id(u, scale, label_key);
+    v = scramble_id(v, scale, label_key);
     keys[2 * e] = loop ? kInvalidKey : ((u << 32) | v);
     keys[2 * e + 1] = loop ? kInvalidKey : ((v << 32) | u);
 }
@@ -488,29 +495,32 @@ int gcn_check_indices(int64_t nnz, const int32_t* indices, int64_t n_cols, void*
     return GCN_OK;
 }
 
-int gcn_rmat_csr_bound(int scale, int edge_factor, int64_t* nnz_capacity, size_t* workspace_bytes) {
+int gcn_rmat_csr_bound(int scale, int edge_factor, int flags, int64_t* nnz_capacity, size_t* workspace_bytes) {
     if (scale < 1 || scale > 30 || edge_factor < 1 || !nnz_capacity || !workspace_bytes)
         return fail(GCN_ERR_BAD_ARG, "bad argument");
-    const int64_t m = 2 * ((int64_t)edge_factor << scale);
+    const int64_t m = 2 * ((int64_t)edge_factor << scale) + ((flags & GCN_ADD_SELF_LOOPS) ? ((int64_t)1 << scale) : 0);
     *nnz_capacity = m;
     *workspace_bytes = sort_scratch_bytes(m, false);
     return GCN_OK;
 }
 
-int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int64_t* indptr_out, int32_t* indices_out,
+int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int flags, int64_t* indptr_out, int32_t* indices_out,
                  int64_t* nnz_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (scale < 1 || scale > 30 || edge_factor < 1 || !indptr_out || !indices_out || !nnz_out)
         return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (flags & ~GCN_ADD_SELF_LOOPS) return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_pairs = (int64_t)edge_factor << scale;
-    const int64_t m = 2 * n_pairs;
+    const int64_t n_loops = (flags & GCN_ADD_SELF_LOOPS) ? ((int64_t)1 << scale) : 0;
+    const int64_t m = 2 * n_pairs + n_loops;
     SortScratch s;
     int rc = carve_scratch(workspace, workspace_bytes, m, false, &s);
     if (rc != GCN_OK) return rc;
     const uint32_t ta = (uint32_t)(0.57 * 4294967296.0);
     const uint32_t tb = (uint32_t)((0.57 + 0.19) * 4294967296.0);
     const uint32_t tc = (uint32_t)((0.57 + 0.19 + 0.19) * 4294967296.0);
-    rmat_keys_kernel<<<grid_for(n_pairs), kBlock, 0, st>>>(scale, n_pairs, stream_key(seed, 0), ta, tb, tc, s.keys_a);
+    rmat_keys_kernel<<<grid_for(n_pairs + n_loops), kBlock, 0, st>>>(scale, n_pairs, n_loops, stream_key(seed, 0),
+                                                                     stream_key(seed, 1), ta, tb, tc, s.keys_a);
     GCN_LAUNCH_CHECK();
     // invalid keys are all ones and must sort last: sort on all 64 bits
     return sorted_merge_to_csr(&s, m, false, 2, 64u, (int64_t)1 << scale, indptr_out, indices_out, nullptr, nnz_out,

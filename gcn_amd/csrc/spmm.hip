@@ -24,6 +24,8 @@ struct gcn_spmm_plan {
     int32_t* long_row;    // [n_long] rows longer than kSplitNnz, ascending
     int64_t* long_chunk;  // [n_long + 1] first chunk of each long row
     int32_t* chunk_long;  // [n_chunks] long-row slot of each chunk
+    int timing;           // record events around the kernels of every product
+    hipEvent_t ev[3];     // start, after the row kernel, after the long-row reduction
 };
 
 namespace gcn {
@@ -198,16 +200,17 @@ __device__ __forceinline__ void store_row(float* dst, const int (&col)[VPL], con
 
 // rows of ordinary length; one wave per strip
 template <int LPR, int VEC, int VPL, bool DROPOUT>
-__global__ __launch_bounds__(kBlock) void spmm_strips_kernel(
-    int64_t n_strips, const int32_t* __restrict__ strip_row, const int64_t* __restrict__ indptr,
-    const int32_t* __restrict__ indices, const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
-    uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu, DropArgs dr) {
+__device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, const int32_t* __restrict__ strip_row,
+                                             const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                             const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
+                                             uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
+                                             const DropArgs& dr) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;  // columns covered per pass
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
-    const int64_t strip = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t strip = block * (kBlock / 64) + (threadIdx.x >> 6);
     if (strip >= n_strips) return;
     const int r_lo = strip_row[strip];
     const int r_hi = strip_row[strip + 1];
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void spmm_strips_kernel(
         for (int r = r_lo + grp; r < r_hi; r += kGroups) {
             const int64_t k0 = indptr[r];
             const int64_t k1 = indptr[r + 1];
-            if (k1 - k0 > kSplitNnz) continue;  // summed by the chunk kernels
+            if (k1 - k0 > kSplitNnz) continue;  // summed chunk-wise
             float acc[VPL][VEC];
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
@@ -238,17 +241,18 @@ __global__ __launch_bounds__(kBlock) void spmm_strips_kernel(
 
 // one lane group per chunk of a long row -> partial row in the workspace
 template <int LPR, int VEC, int VPL, bool DROPOUT>
-__global__ __launch_bounds__(kBlock) void spmm_chunks_kernel(
-    int64_t n_chunks, const int32_t* __restrict__ chunk_long, const int32_t* __restrict__ long_row,
-    const int64_t* __restrict__ long_chunk, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-    const float* __restrict__ vals, int64_t f, const float* __restrict__ b, uint32_t ldb, float* __restrict__ part,
-    int64_t ldp, DropArgs dr) {
+__device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, const int32_t* __restrict__ chunk_long,
+                                             const int32_t* __restrict__ long_row,
+                                             const int64_t* __restrict__ long_chunk,
+                                             const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                             const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
+                                             uint32_t ldb, float* __restrict__ part, int64_t ldp, const DropArgs& dr) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
-    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t wave = block * (kBlock / 64) + (threadIdx.x >> 6);
     const int64_t chunk = wave * kGroups + grp;
     if (chunk >= n_chunks) return;
     const int li = chunk_long[chunk];
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(kBlock) void spmm_chunks_kernel(
     const int64_t row_end = indptr[r + 1];
     const int64_t k1 = (k0 + kSplitNnz < row_end) ? k0 + kSplitNnz : row_end;
     for (int64_t col0 = 0; col0 < f; col0 += kTile) {
-        int col[VPL];   // first column of each of this lane's vectors
-        int lcol[VPL];  // the column it loads from: clamped into the row so that idle lanes load valid data
+        int col[VPL];
+        int lcol[VPL];
         bool on[VPL];
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -274,6 +278,33 @@ __global__ __launch_bounds__(kBlock) void spmm_chunks_kernel(
         accumulate_range<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
         store_row<VEC, VPL>(part + chunk * ldp, col, on, acc, false);
     }
+}
+
+struct PlanView {
+    int64_t n_strips, n_chunks, chunk_blocks;
+    const int32_t* strip_row;
+    const int32_t* chunk_long;
+    const int32_t* long_row;
+    const int64_t* long_chunk;
+};
+
+// The whole product in one launch: the blocks that sum chunks of long rows come first (they are
+// the longest work items), the strip blocks after them.
+template <int LPR, int VEC, int VPL, bool DROPOUT>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const int64_t* __restrict__ indptr,
+                                                           const int32_t* __restrict__ indices,
+                                                           const float* __restrict__ vals, int64_t f,
+                                                           const float* __restrict__ b, uint32_t ldb,
+                                                           float* __restrict__ c, int64_t ldc,
+                                                           float* __restrict__ part, int64_t ldp, int relu,
+                                                           DropArgs dr) {
+    const int64_t block = blockIdx.x;
+    if (block < pv.chunk_blocks)
+        chunks_block<LPR, VEC, VPL, DROPOUT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
+                                             indices, vals, f, b, ldb, part, ldp, dr);
+    else
+        strips_block<LPR, VEC, VPL, DROPOUT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
+                                             vals, f, b, ldb, c, ldc, relu, dr);
 }
 
 // partial rows of each long row, added in chunk order; one wave per long row
@@ -319,23 +350,28 @@ static int launch_variant(const SpmmCall& a) {
     const gcn_spmm_plan* p = a.plan;
     constexpr int kWaves = kBlock / 64;
     constexpr int kGroups = 64 / LPR;
-    {
-        const unsigned grid = (unsigned)ceil_div(p->n_strips, kWaves);
-        spmm_strips_kernel<LPR, VEC, VPL, DROPOUT><<<grid, kBlock, 0, a.st>>>(
-            p->n_strips, p->strip_row, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.relu, a.dr);
-        GCN_LAUNCH_CHECK();
-    }
+    PlanView pv;
+    pv.n_strips = p->n_strips;
+    pv.n_chunks = p->n_chunks;
+    pv.chunk_blocks = ceil_div(ceil_div(p->n_chunks, kGroups), kWaves);
+    pv.strip_row = p->strip_row;
+    pv.chunk_long = p->chunk_long;
+    pv.long_row = p->long_row;
+    pv.long_chunk = p->long_chunk;
+    const int64_t grid = pv.chunk_blocks + ceil_div(p->n_strips, kWaves);
+    if (grid > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
+    if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[0], a.st));
+    spmm_rows_kernel<LPR, VEC, VPL, DROPOUT><<<(unsigned)grid, kBlock, 0, a.st>>>(
+        pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr);
+    GCN_LAUNCH_CHECK();
+    if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[1], a.st));
     if (p->n_chunks > 0) {
-        const unsigned grid = (unsigned)ceil_div(ceil_div(p->n_chunks, kGroups), kWaves);
-        spmm_chunks_kernel<LPR, VEC, VPL, DROPOUT><<<grid, kBlock, 0, a.st>>>(
-            p->n_chunks, p->chunk_long, p->long_row, p->long_chunk, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb,
-            a.part, a.ldp, a.dr);
-        GCN_LAUNCH_CHECK();
         const unsigned grid2 = (unsigned)ceil_div(p->n_long, kWaves);
         spmm_long_reduce_kernel<<<grid2, kBlock, 0, a.st>>>(p->n_long, p->long_row, p->long_chunk, a.f, a.part,
                                                             a.ldp, a.c, a.ldc, a.relu);
         GCN_LAUNCH_CHECK();
     }
+    if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[2], a.st));
     return GCN_OK;
 }
 
@@ -419,6 +455,8 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
     p->long_row = nullptr;
     p->long_chunk = nullptr;
     p->chunk_long = nullptr;
+    p->timing = 0;
+    p->ev[0] = p->ev[1] = p->ev[2] = nullptr;
     int32_t* d_rows = nullptr;
     int64_t *d_starts = nullptr, *d_ends = nullptr;
     unsigned long long* d_count = nullptr;
@@ -508,7 +546,26 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan* plan) {
     (void)hipFree(plan->long_row);
     (void)hipFree(plan->long_chunk);
     (void)hipFree(plan->chunk_long);
+    for (int i = 0; i < 3; ++i)
+        if (plan->ev[i]) (void)hipEventDestroy(plan->ev[i]);
     delete plan;
+    return GCN_OK;
+}
+
+int gcn_spmm_plan_set_timing(gcn_spmm_plan* plan, int enable) {
+    if (!plan) return fail(GCN_ERR_BAD_ARG, "plan is null");
+    if (enable && !plan->ev[0])
+        for (int i = 0; i < 3; ++i) GCN_HIP_TRY(hipEventCreate(&plan->ev[i]));
+    plan->timing = enable ? 1 : 0;
+    return GCN_OK;
+}
+
+int gcn_spmm_plan_last_timing(const gcn_spmm_plan* plan, float* ms2) {
+    if (!plan || !ms2) return fail(GCN_ERR_BAD_ARG, "null argument");
+    if (!plan->timing || !plan->ev[0]) return fail(GCN_ERR_BAD_ARG, "timing is not enabled on this plan");
+    GCN_HIP_TRY(hipEventSynchronize(plan->ev[2]));
+    GCN_HIP_TRY(hipEventElapsedTime(&ms2[0], plan->ev[0], plan->ev[1]));
+    GCN_HIP_TRY(hipEventElapsedTime(&ms2[1], plan->ev[1], plan->ev[2]));
     return GCN_OK;
 }
 

@@ -57,6 +57,16 @@ class SpmmPlan(object):
         self.n_strips, self.n_long_rows, self.n_chunks, self.split_nnz = (int(v) for v in info)
         self._ws = {}
 
+    def set_timing(self, enable=True):
+        """Record HIP events around the kernels of every product on this plan."""
+        _lib.call('gcn_spmm_plan_set_timing', self.handle, 1 if enable else 0)
+
+    def last_timing(self):
+        """(row kernel ms, long-row reduction ms) of the last product; waits for it."""
+        ms = (ctypes.c_float * 2)()
+        _lib.call('gcn_spmm_plan_last_timing', self.handle, ms)
+        return float(ms[0]), float(ms[1])
+
     def workspace(self, f, device):
         nbytes = ctypes.c_size_t()
         _lib.call('gcn_spmm_plan_workspace_bytes', self.handle, f, ctypes.byref(nbytes))
@@ -193,11 +203,12 @@ def _norm_code(type):
     raise ValueError('Invalid normalisation type: ' + str(type))
 
 
-def normalize_values(indptr, indices, vals, d, type='sym'):
-    """float64 and float32 values of normalize_adj on CSR storage (see gcn_hip.h)."""
+def normalize_values(indptr, indices, vals, d, type='sym', want64=True):
+    """(float64, float32) values of normalize_adj on CSR storage (see gcn_hip.h);
+    ``want64=False`` skips the float64 copy."""
     n = indptr.numel() - 1
     nnz = indices.numel()
-    out64 = torch.empty(nnz, dtype=torch.float64, device=indptr.device)
+    out64 = torch.empty(nnz, dtype=torch.float64, device=indptr.device) if want64 else None
     out32 = torch.empty(nnz, dtype=torch.float32, device=indptr.device)
     _lib.call('gcn_normalize_adj', n, nnz, _p(indptr), _p(indices), _p(vals), _p(d), _norm_code(type), _p(out64),
               _p(out32), _stream())
@@ -225,17 +236,19 @@ def csr_transpose(a):
 # --------------------------------------------------------------------------- #
 # synthetic inputs
 # --------------------------------------------------------------------------- #
-def rmat_csr(scale, edge_factor=16, seed=42, device='cuda'):
-    """CSR structure (indptr int64, indices int32) of the symmetrised, deduplicated R-MAT graph."""
+def rmat_csr(scale, edge_factor=16, seed=42, self_loops=False, device='cuda'):
+    """CSR structure (indptr int64, indices int32) of the symmetrised, deduplicated R-MAT graph;
+    with ``self_loops`` the structure of A + I."""
+    flags = _lib.GCN_ADD_SELF_LOOPS if self_loops else 0
     cap, ws_bytes = ctypes.c_int64(), ctypes.c_size_t()
-    _lib.call('gcn_rmat_csr_bound', scale, edge_factor, ctypes.byref(cap), ctypes.byref(ws_bytes))
+    _lib.call('gcn_rmat_csr_bound', scale, edge_factor, flags, ctypes.byref(cap), ctypes.byref(ws_bytes))
     n = 1 << scale
     indptr = torch.empty(n + 1, dtype=torch.int64, device=device)
     indices = torch.empty(cap.value, dtype=torch.int32, device=device)
     nnz_out = torch.zeros(1, dtype=torch.int64, device=device)
     ws = _workspace(ws_bytes.value, indptr.device)
-    _lib.call('gcn_rmat_csr', scale, edge_factor, seed, _p(indptr), _p(indices), _p(nnz_out), _p(ws), ws.numel(),
-              _stream())
+    _lib.call('gcn_rmat_csr', scale, edge_factor, seed, flags, _p(indptr), _p(indices), _p(nnz_out), _p(ws),
+              ws.numel(), _stream())
     nnz = int(nnz_out.item())
     del ws
     return indptr, indices[:nnz].clone()

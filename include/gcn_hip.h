@@ -106,13 +106,16 @@ int gcn_check_indices(int64_t nnz, const int32_t* indices, int64_t n_cols, void*
  * Synthetic inputs for measurement (the reference has no generator).         *
  * ------------------------------------------------------------------------- */
 
-int gcn_rmat_csr_bound(int scale, int edge_factor, int64_t* nnz_capacity, size_t* workspace_bytes);
+int gcn_rmat_csr_bound(int scale, int edge_factor, int flags, int64_t* nnz_capacity, size_t* workspace_bytes);
 
 /* R-MAT (a,b,c,d)=(0.57,0.19,0.19,0.05), edge_factor*2^scale generated pairs,
- * self-loops dropped, symmetrised, deduplicated -> CSR structure of a simple
- * undirected graph (the kind nx.from_dict_of_lists builds at gcn/utils.py:123).
- * Integer-only, counter-based: identical to the CPU oracle bit for bit. */
-int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int64_t* indptr_out, int32_t* indices_out,
+ * vertex ids scrambled by a fixed bijection (so that contiguous row blocks carry
+ * equal work), self-loops dropped, symmetrised, deduplicated -> CSR structure of
+ * a simple undirected graph (the kind nx.from_dict_of_lists builds at
+ * gcn/utils.py:123).  flags: GCN_ADD_SELF_LOOPS also inserts every (i, i), giving
+ * the structure of A + I (all values 1).  Integer-only, counter-based: identical
+ * to the CPU oracle bit for bit. */
+int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int flags, int64_t* indptr_out, int32_t* indices_out,
                  int64_t* nnz_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[i] = (int32(h >> 32) >> 8) * 2^-23 in [-1,1), h = splitmix(key(seed) ^ i). */
@@ -132,6 +135,12 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan* plan);
 /* host-side facts about a plan: what[0]=n_strips, [1]=n_long_rows, [2]=n_chunks, [3]=split threshold */
 int gcn_spmm_plan_info(const gcn_spmm_plan* plan, int64_t* what4);
 int gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan* plan, int64_t f, size_t* workspace_bytes);
+/* Measurement hook (the reference times its step with time.time(), train.py:203-205): when enabled,
+ * every product on this plan records HIP events on its stream around its kernels;
+ * gcn_spmm_plan_last_timing waits for the last product and returns ms2[0] = the row kernel,
+ * ms2[1] = the long-row reduction.  [sync] */
+int gcn_spmm_plan_set_timing(gcn_spmm_plan* plan, int enable);
+int gcn_spmm_plan_last_timing(const gcn_spmm_plan* plan, float* ms2);
 
 /* C[n_rows x f] = A . B, A in CSR, B [n_cols x f]: `dot(x, y, sparse=True)`
  * = tf.sparse_tensor_dense_matmul at gcn/layers.py:28-31, called at

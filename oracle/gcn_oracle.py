@@ -94,16 +94,35 @@ def rmat_pairs(scale, edge_factor=16, seed=42):
     return u, v
 
 
-def rmat_csr(scale, edge_factor=16, seed=42):
-    """Simple undirected graph: drop self-loops, symmetrise, sort, dedupe -> CSR structure."""
+def scramble_id(v, bits, key):
+    """Fixed bijection on [0, 2^bits): odd multiplications and xor-shifts modulo 2^bits."""
+    mask = _U64((1 << bits) - 1)
+    sh = _U64((bits + 1) // 2)
+    with np.errstate(over='ignore'):
+        x = (np.asarray(v, dtype=np.uint64) + _U64(key)) & mask
+        x = (x * _GOLD) & mask
+        x = x ^ (x >> sh)
+        x = (x * _M1) & mask
+        x = x ^ (x >> sh)
+    return x
+
+
+def rmat_csr(scale, edge_factor=16, seed=42, self_loops=False):
+    """Simple undirected graph: scramble ids, drop self-loops, symmetrise, sort, dedupe -> CSR
+    structure; ``self_loops`` adds every (i, i) (the structure of A + I)."""
     u, v = rmat_pairs(scale, edge_factor, seed)
     keep = u != v
-    u, v = u[keep], v[keep]
+    label_key = stream_key(seed, 1)
+    u = scramble_id(u[keep], scale, label_key).astype(np.int64)
+    v = scramble_id(v[keep], scale, label_key).astype(np.int64)
     keys = np.concatenate([(u << 32) | v, (v << 32) | u])
+    n = 1 << scale
+    if self_loops:
+        d = np.arange(n, dtype=np.int64)
+        keys = np.concatenate([keys, (d << 32) | d])
     keys = np.unique(keys)
     rows = (keys >> 32).astype(np.int64)
     cols = (keys & 0xFFFFFFFF).astype(np.int32)
-    n = 1 << scale
     indptr = np.zeros(n + 1, dtype=np.int64)
     np.add.at(indptr, rows + 1, 1)
     return np.cumsum(indptr), cols

@@ -179,16 +179,17 @@ def test_check_indices_raises_like_the_reference_kernel():
 
 
 @pytest.mark.parametrize('scale,edge_factor', [(8, 16), (12, 16), (14, 4)])
-def test_rmat_matches_oracle_bit_for_bit(oracle, scale, edge_factor):
+@pytest.mark.parametrize('self_loops', [False, True])
+def test_rmat_matches_oracle_bit_for_bit(oracle, scale, edge_factor, self_loops):
     from gcn_amd import sparse
-    indptr, indices = sparse.rmat_csr(scale, edge_factor, seed=42)
-    rip, rix = oracle.rmat_csr(scale, edge_factor, seed=42)
+    indptr, indices = sparse.rmat_csr(scale, edge_factor, seed=42, self_loops=self_loops)
+    rip, rix = oracle.rmat_csr(scale, edge_factor, seed=42, self_loops=self_loops)
     assert np.array_equal(indptr.cpu().numpy(), rip)
     assert np.array_equal(indices.cpu().numpy(), rix)
-    # simple undirected graph: no self-loops, symmetric, strictly ascending columns
+    # simple undirected graph: symmetric, strictly ascending columns, diagonal only when asked for
     ip, ix = indptr.cpu().numpy(), indices.cpu().numpy()
     rows = np.repeat(np.arange(1 << scale), np.diff(ip))
-    assert not np.any(rows == ix)
+    assert int((rows == ix).sum()) == ((1 << scale) if self_loops else 0)
     key = rows.astype(np.int64) << 32 | ix
     assert np.all(np.diff(key) > 0)
     assert np.array_equal(np.sort(ix.astype(np.int64) << 32 | rows), key)

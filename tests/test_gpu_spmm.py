@@ -145,12 +145,17 @@ def test_rmat_product_properties(oracle):
     indptr, indices = sparse.rmat_csr(scale, 16, seed=42)
     n = 1 << scale
     ones = torch.ones(indices.numel(), dtype=torch.float64, device='cuda')
-    # A + I through the preprocessing kernels
+    # A + I through the preprocessing kernels ...
     rows = torch.repeat_interleave(torch.arange(n, device='cuda'), indptr[1:] - indptr[:-1])
     ip, ix, vals = sparse.coo_to_csr(n, n, rows, indices, ones, add_self_loops=True)
+    # ... equals the structure the generator emits directly
+    ip_direct, ix_direct = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+    assert torch.equal(ip, ip_direct) and torch.equal(ix, ix_direct) and bool((vals == 1).all())
     deg = sparse.row_sums(ip, vals)
+    assert torch.equal(deg, sparse.row_sums(ip, None))
     d = sparse.degree_scale(deg, 'sym')
     _, v32 = sparse.normalize_values(ip, ix, vals, d, 'sym')
+    assert torch.equal(v32, sparse.normalize_values(ip, ix, None, d, 'sym', want64=False)[1])
     a = sparse.DeviceCSR(n, n, ip, ix, v32)
     assert a.plan.n_long_rows > 0
     b = sparse.synthetic_dense(n, 64, seed=7)
