@@ -22,16 +22,24 @@ static inline unsigned bits_for(uint64_t v) {  // number of bits needed to hold 
     return b ? b : 1;
 }
 
-static inline dim3 grid_for(int64_t n) { return dim3((unsigned)ceil_div(n > 0 ? n : 1, kBlock)); }
+// Grids are capped (gridDim.x * blockDim.x must stay below 2^32); kernels walk their range with a grid stride.
+constexpr int64_t kMaxBlocks = 1 << 20;
+static inline dim3 grid_for(int64_t n) {
+    const int64_t blocks = ceil_div(n > 0 ? n : 1, kBlock);
+    return dim3((unsigned)(blocks < kMaxBlocks ? blocks : kMaxBlocks));
+}
+#define GCN_GRID_STRIDE(i, n)                                                              \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); \
+         i += (int64_t)gridDim.x * blockDim.x)
 
 // ------------------------------------------------------------------------------------------------
 // sorted keys (row << 32 | col) -> CSR, merging equal keys
 // ------------------------------------------------------------------------------------------------
 __global__ void head_flags_kernel(int64_t m, const uint64_t* __restrict__ keys, int64_t* __restrict__ pos) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const uint64_t k = keys[i];
-    pos[i] = (k != kInvalidKey && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+    GCN_GRID_STRIDE(i, m) {
+        const uint64_t k = keys[i];
+        pos[i] = (k != kInvalidKey && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+    }
 }
 
 // pos holds the EXCLUSIVE scan of the head flags.  One thread per sorted element; heads write.
@@ -40,34 +48,34 @@ __global__ void scatter_unique_kernel(int64_t m, int64_t n_rows, const uint64_t*
                                       const double* __restrict__ vals, const int64_t* __restrict__ pos, int mode,
                                       int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
                                       double* __restrict__ vals_out, int64_t* __restrict__ nnz_out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const uint64_t k = keys[i];
-    if (k == kInvalidKey) {
-        if (i == 0) {  // no valid entry at all
-            for (int64_t q = 0; q <= n_rows; ++q) indptr[q] = 0;
-            *nnz_out = 0;
+    GCN_GRID_STRIDE(i, m) {
+        const uint64_t k = keys[i];
+        if (k == kInvalidKey) {
+            if (i == 0) {  // no valid entry at all
+                for (int64_t q = 0; q <= n_rows; ++q) indptr[q] = 0;
+                *nnz_out = 0;
+            }
+            continue;
         }
-        return;
-    }
-    const int64_t row = (int64_t)(k >> 32);
-    const bool head = (i == 0) || (keys[i - 1] != k);
-    const int64_t j = pos[i] - (head ? 0 : 1);  // index of this element's unique entry
-    if (head) {
-        indices[j] = (int32_t)(uint32_t)k;
-        if (mode != 2) {
-            double s = (mode == 0) ? vals[i] : 1.0;
-            for (int64_t t = i + 1; t < m && keys[t] == k; ++t) s += (mode == 0) ? vals[t] : 1.0;
-            vals_out[j] = s;
+        const int64_t row = (int64_t)(k >> 32);
+        const bool head = (i == 0) || (keys[i - 1] != k);
+        const int64_t j = pos[i] - (head ? 0 : 1);  // index of this element's unique entry
+        if (head) {
+            indices[j] = (int32_t)(uint32_t)k;
+            if (mode != 2) {
+                double s = (mode == 0) ? vals[i] : 1.0;
+                for (int64_t t = i + 1; t < m && keys[t] == k; ++t) s += (mode == 0) ? vals[t] : 1.0;
+                vals_out[j] = s;
+            }
+            const int64_t prev_row = (i == 0) ? -1 : (int64_t)(keys[i - 1] >> 32);
+            for (int64_t q = prev_row + 1; q <= row; ++q) indptr[q] = j;  // rows that start here (and empty ones before)
         }
-        const int64_t prev_row = (i == 0) ? -1 : (int64_t)(keys[i - 1] >> 32);
-        for (int64_t q = prev_row + 1; q <= row; ++q) indptr[q] = j;  // rows that start here (and empty ones before)
-    }
-    const bool last = (i == m - 1) || (keys[i + 1] == kInvalidKey);
-    if (last) {
-        const int64_t total = j + 1;
-        for (int64_t q = row + 1; q <= n_rows; ++q) indptr[q] = total;
-        *nnz_out = total;
+        const bool last = (i == m - 1) || (keys[i + 1] == kInvalidKey);
+        if (last) {
+            const int64_t total = j + 1;
+            for (int64_t q = row + 1; q <= n_rows; ++q) indptr[q] = total;
+            *nnz_out = total;
+        }
     }
 }
 
@@ -160,15 +168,15 @@ static int sorted_merge_to_csr(SortScratch* s, int64_t m, bool valued, int mode,
 __global__ void pack_coo_keys_kernel(int64_t nnz_in, int64_t n_loops, const int32_t* __restrict__ rows,
                                      const int32_t* __restrict__ cols, const double* __restrict__ vals,
                                      uint64_t* __restrict__ keys, double* __restrict__ kvals) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nnz_in + n_loops) return;
-    if (i < nnz_in) {
-        keys[i] = ((uint64_t)(uint32_t)rows[i] << 32) | (uint32_t)cols[i];
-        if (kvals) kvals[i] = vals ? vals[i] : 1.0;
-    } else {
-        const uint64_t d = (uint64_t)(i - nnz_in);
-        keys[i] = (d << 32) | d;  // the sp.eye(n) entry
-        if (kvals) kvals[i] = 1.0;
+    GCN_GRID_STRIDE(i, nnz_in + n_loops) {
+        if (i < nnz_in) {
+            keys[i] = ((uint64_t)(uint32_t)rows[i] << 32) | (uint32_t)cols[i];
+            if (kvals) kvals[i] = vals ? vals[i] : 1.0;
+        } else {
+            const uint64_t d = (uint64_t)(i - nnz_in);
+            keys[i] = (d << 32) | d;  // the sp.eye(n) entry
+            if (kvals) kvals[i] = 1.0;
+        }
     }
 }
 
@@ -177,13 +185,13 @@ __global__ void pack_coo_keys_kernel(int64_t nnz_in, int64_t n_loops, const int3
 // ------------------------------------------------------------------------------------------------
 __global__ void rows_to_indptr_kernel(int64_t n_rows, int64_t nnz, const int32_t* __restrict__ rows,
                                       int64_t* __restrict__ indptr) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nnz) return;
-    const int64_t r = rows[k];
-    const int64_t rp = (k == 0) ? -1 : (int64_t)rows[k - 1];
-    for (int64_t q = rp + 1; q <= r; ++q) indptr[q] = k;
-    if (k == nnz - 1)
-        for (int64_t q = r + 1; q <= n_rows; ++q) indptr[q] = nnz;
+    GCN_GRID_STRIDE(k, nnz) {
+        const int64_t r = rows[k];
+        const int64_t rp = (k == 0) ? -1 : (int64_t)rows[k - 1];
+        for (int64_t q = rp + 1; q <= r; ++q) indptr[q] = k;
+        if (k == nnz - 1)
+            for (int64_t q = r + 1; q <= n_rows; ++q) indptr[q] = nnz;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -191,16 +199,16 @@ __global__ void rows_to_indptr_kernel(int64_t n_rows, int64_t nnz, const int32_t
 // ------------------------------------------------------------------------------------------------
 __global__ void row_sums_kernel(int64_t n_rows, const int64_t* __restrict__ indptr, const double* __restrict__ vals,
                                 double* __restrict__ out) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    const int64_t k0 = indptr[r], k1 = indptr[r + 1];
-    double s = 0.0;
-    if (vals) {
-        for (int64_t k = k0; k < k1; ++k) s += vals[k];  // storage order, like the reference's sum(1)
-    } else {
-        s = (double)(k1 - k0);
+    GCN_GRID_STRIDE(r, n_rows) {
+        const int64_t k0 = indptr[r], k1 = indptr[r + 1];
+        double s = 0.0;
+        if (vals) {
+            for (int64_t k = k0; k < k1; ++k) s += vals[k];  // storage order, like the reference's sum(1)
+        } else {
+            s = (double)(k1 - k0);
+        }
+        out[r] = s;
     }
-    out[r] = s;
 }
 
 // x^-0.5 to (all but provably) correct rounding: 1/sqrt(x) refined by one Newton step whose
@@ -215,17 +223,17 @@ __device__ __forceinline__ double inv_sqrt_rn(double x) {
 }
 
 __global__ void degree_scale_kernel(int64_t n, const double* __restrict__ rowsum, int type, double* __restrict__ d) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const double x = rowsum[r];
-    double y;
-    if (type == GCN_NORM_SYM) {
-        y = (x > 0.0) ? inv_sqrt_rn(x) : ((x == 0.0) ? 0.0 : __longlong_as_double(0x7ff8000000000000ll));
-    } else {
-        y = (x != 0.0) ? 1.0 / x : 0.0;
+    GCN_GRID_STRIDE(r, n) {
+        const double x = rowsum[r];
+        double y;
+        if (type == GCN_NORM_SYM) {
+            y = (x > 0.0) ? inv_sqrt_rn(x) : ((x == 0.0) ? 0.0 : __longlong_as_double(0x7ff8000000000000ll));
+        } else {
+            y = (x != 0.0) ? 1.0 / x : 0.0;
+        }
+        if (isinf(y)) y = 0.0;
+        d[r] = y;
     }
-    if (isinf(y)) y = 0.0;
-    d[r] = y;
 }
 
 __device__ __forceinline__ int64_t row_of_entry(const int64_t* __restrict__ indptr, int64_t n_rows, int64_t k) {
@@ -245,20 +253,20 @@ __global__ void normalize_kernel(int64_t n_rows, int64_t nnz, const int64_t* __r
                                  const int32_t* __restrict__ indices, const double* __restrict__ vals,
                                  const double* __restrict__ d, int type, double* __restrict__ out64,
                                  float* __restrict__ out32) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nnz) return;
-    const int64_t r = row_of_entry(indptr, n_rows, k);
-    const double a = vals ? vals[k] : 1.0;
-    double w;
-    if (type == GCN_NORM_SYM) {
-        // adj.dot(D).transpose().dot(D): the stored (r, c) entry becomes result[c, r] = (a * d[c]) * d[r]
-        const double t = __dmul_rn(a, d[indices[k]]);
-        w = __dmul_rn(t, d[r]);
-    } else {
-        w = __dmul_rn(d[r], a);
+    GCN_GRID_STRIDE(k, nnz) {
+        const int64_t r = row_of_entry(indptr, n_rows, k);
+        const double a = vals ? vals[k] : 1.0;
+        double w;
+        if (type == GCN_NORM_SYM) {
+            // adj.dot(D).transpose().dot(D): the stored (r, c) entry becomes result[c, r] = (a * d[c]) * d[r]
+            const double t = __dmul_rn(a, d[indices[k]]);
+            w = __dmul_rn(t, d[r]);
+        } else {
+            w = __dmul_rn(d[r], a);
+        }
+        if (out64) out64[k] = w;
+        if (out32) out32[k] = (float)w;
     }
-    if (out64) out64[k] = w;
-    if (out32) out32[k] = (float)w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -266,10 +274,10 @@ __global__ void normalize_kernel(int64_t n_rows, int64_t nnz, const int64_t* __r
 // ------------------------------------------------------------------------------------------------
 __global__ void transpose_keys_kernel(int64_t nnz, const int32_t* __restrict__ indices, uint32_t* __restrict__ keys,
                                       int64_t* __restrict__ src) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nnz) return;
-    keys[k] = (uint32_t)indices[k];
-    src[k] = k;
+    GCN_GRID_STRIDE(k, nnz) {
+        keys[k] = (uint32_t)indices[k];
+        src[k] = k;
+    }
 }
 
 __global__ void transpose_scatter_kernel(int64_t n_rows, int64_t n_cols, int64_t nnz,
@@ -277,18 +285,18 @@ __global__ void transpose_scatter_kernel(int64_t n_rows, int64_t n_cols, int64_t
                                          const int64_t* __restrict__ src, const void* __restrict__ vals, int val_bytes,
                                          int64_t* __restrict__ t_indptr, int32_t* __restrict__ t_indices,
                                          void* __restrict__ t_vals, int64_t* __restrict__ perm) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nnz) return;
-    const int64_t k = src[j];
-    t_indices[j] = (int32_t)row_of_entry(indptr, n_rows, k);
-    if (val_bytes == 4) ((float*)t_vals)[j] = ((const float*)vals)[k];
-    if (val_bytes == 8) ((double*)t_vals)[j] = ((const double*)vals)[k];
-    if (perm) perm[j] = k;
-    const int64_t c = keys[j];
-    const int64_t cp = (j == 0) ? -1 : (int64_t)keys[j - 1];
-    for (int64_t q = cp + 1; q <= c; ++q) t_indptr[q] = j;
-    if (j == nnz - 1)
-        for (int64_t q = c + 1; q <= n_cols; ++q) t_indptr[q] = nnz;
+    GCN_GRID_STRIDE(j, nnz) {
+        const int64_t k = src[j];
+        t_indices[j] = (int32_t)row_of_entry(indptr, n_rows, k);
+        if (val_bytes == 4) ((float*)t_vals)[j] = ((const float*)vals)[k];
+        if (val_bytes == 8) ((double*)t_vals)[j] = ((const double*)vals)[k];
+        if (perm) perm[j] = k;
+        const int64_t c = keys[j];
+        const int64_t cp = (j == 0) ? -1 : (int64_t)keys[j - 1];
+        for (int64_t q = cp + 1; q <= c; ++q) t_indptr[q] = j;
+        if (j == nnz - 1)
+            for (int64_t q = c + 1; q <= n_cols; ++q) t_indptr[q] = nnz;
+    }
 }
 
 static size_t transpose_prim_bytes(int64_t nnz) {
@@ -304,10 +312,10 @@ static size_t transpose_prim_bytes(int64_t nnz) {
 // ------------------------------------------------------------------------------------------------
 __global__ void check_indices_kernel(int64_t nnz, const int32_t* __restrict__ indices, int64_t n_cols,
                                      int* __restrict__ bad) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nnz) return;
-    const int64_t c = indices[k];
-    if (c < 0 || c >= n_cols) atomicOr(bad, 1);
+    GCN_GRID_STRIDE(k, nnz) {
+        const int64_t c = indices[k];
+        if (c < 0 || c >= n_cols) atomicOr(bad, 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -315,32 +323,32 @@ __global__ void check_indices_kernel(int64_t nnz, const int32_t* __restrict__ in
 // ------------------------------------------------------------------------------------------------
 __global__ void rmat_keys_kernel(int scale, int64_t n_pairs, int64_t n_loops, uint64_t key, uint64_t label_key,
                                  uint32_t ta, uint32_t tb, uint32_t tc, uint64_t* __restrict__ keys) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_pairs + n_loops) return;
-    if (e >= n_pairs) {  // the diagonal of A + I
-        const uint64_t d = (uint64_t)(e - n_pairs);
-        keys[2 * n_pairs + d] = (d << 32) | d;
-        return;
+    GCN_GRID_STRIDE(e, n_pairs + n_loops) {
+        if (e >= n_pairs) {  // the diagonal of A + I
+            const uint64_t d = (uint64_t)(e - n_pairs);
+            keys[2 * n_pairs + d] = (d << 32) | d;
+            continue;
+        }
+        uint64_t u = 0, v = 0;
+        for (int level = 0; level < scale; ++level) {
+            const uint32_t r = (uint32_t)(sm64(key ^ ((uint64_t)e * (uint64_t)scale + (uint64_t)level)) >> 32);
+            const uint32_t q = (r >= ta) + (r >= tb) + (r >= tc);
+            u = (u << 1) | (q >> 1);
+            v = (v << 1) | (q & 1);
+        }
+        const bool loop = (u == v);
+        u = scramble_id(u, scale, label_key);
+        v = scramble_id(v, scale, label_key);
+        keys[2 * e] = loop ? kInvalidKey : ((u << 32) | v);
+        keys[2 * e + 1] = loop ? kInvalidKey : ((v << 32) | u);
     }
-    uint64_t u = 0, v = 0;
-    for (int level = 0; level < scale; ++level) {
-        const uint32_t r = (uint32_t)(sm64(key ^ ((uint64_t)e * (uint64_t)scale + (uint64_t)level)) >> 32);
-        const uint32_t q = (r >= ta) + (r >= tb) + (r >= tc);
-        u = (u << 1) | (q >> 1);
-        v = (v << 1) | (q & 1);
-    }
-    const bool loop = (u == v);
-    u = scramble_id(u, scale, label_key);
-    v = scramble_id(v, scale, label_key);
-    keys[2 * e] = loop ? kInvalidKey : ((u << 32) | v);
-    keys[2 * e + 1] = loop ? kInvalidKey : ((v << 32) | u);
 }
 
 __global__ void fill_synthetic_kernel(int64_t count, uint64_t key, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const int32_t hi = (int32_t)(uint32_t)(sm64(key ^ (uint64_t)i) >> 32);
-    out[i] = (float)(hi >> 8) * 1.1920928955078125e-07f;  // 2^-23
+    GCN_GRID_STRIDE(i, count) {
+        const int32_t hi = (int32_t)(uint32_t)(sm64(key ^ (uint64_t)i) >> 32);
+        out[i] = (float)(hi >> 8) * 1.1920928955078125e-07f;  // 2^-23
+    }
 }
 
 }  // namespace gcn
