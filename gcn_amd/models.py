@@ -1,0 +1,214 @@
+"""The model of the reference (gcn/models.py:6-128) on the HIP layers.
+
+``GCN_MLP(model_config, placeholders, input_dim)`` builds the layer stack named by
+``model_config['connection']`` and exposes ``outputs``, ``prediction``, ``loss``, ``accuracy``,
+``accuracy_of_class``, ``opt_op`` and ``summary`` as fetch handles for ``Session.run``.
+Only graph-convolution layers ('c') are in scope; the other connection letters raise.
+"""
+from copy import copy
+
+import numpy as np
+import torch
+
+from . import graph, sparse
+from .layers import GraphConvolution, relu
+from .metrics import masked_accuracy, masked_softmax_cross_entropy
+
+
+class TfAdam(object):
+    """tf.train.AdamOptimizer(learning_rate) as built at gcn/models.py:35-38 (beta1 0.9,
+    beta2 0.999, epsilon 1e-8).  TensorFlow folds the bias corrections into the step size and
+    adds epsilon to sqrt(v) uncorrected: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);
+    var -= lr_t * m / (sqrt(v) + eps)."""
+
+    def __init__(self, params, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.params = list(params)
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, grads):
+        self.t += 1
+        lr_t = self.lr * float(np.sqrt(1.0 - self.b2 ** self.t)) / (1.0 - self.b1 ** self.t)
+        for p, g, m, v in zip(self.params, grads, self.m, self.v):
+            m.add_(g - m, alpha=1.0 - self.b1)
+            v.add_(g * g - v, alpha=1.0 - self.b2)
+            p.addcdiv_(m, v.sqrt().add_(self.eps), value=-lr_t)
+
+
+class GCN_MLP(object):
+    def __init__(self, model_config, placeholders, input_dim):
+        self.model_config = model_config
+        self.name = model_config['name']
+        if not self.name:
+            self.name = self.__class__.__name__.lower()
+        self.logging = False
+
+        self.vars = {}
+        self.layers = []
+        self.activations = []
+        self.act = [relu for _ in range(len(self.model_config['connection']))]
+        self.act[-1] = lambda x: x
+
+        self.placeholders = placeholders
+        self.inputs = placeholders['features']
+        self.inputs._my_input_dim = input_dim
+        self.input_dim = input_dim
+        self.output_dim = placeholders['labels'].get_shape().as_list()[1]
+        self.global_step = 0
+        self.optimizer = None
+        self._run_counter = 0
+        self._device_cache = {}
+
+        self.outputs = graph.Fetch(self, 'outputs')
+        self.prediction = graph.Fetch(self, 'prediction')
+        self.loss = graph.Fetch(self, 'loss')
+        self.accuracy = graph.Fetch(self, 'accuracy')
+        self.accuracy_of_class = [graph.Fetch(self, 'accuracy_of_class', i) for i in range(self.output_dim)]
+        self.opt_op = graph.Fetch(self, 'opt_op')
+        self.summary = graph.Fetch(self, 'summary')
+
+        self.build()
+
+    # ------------------------------------------------------------------ #
+    def build(self):
+        """Layer construction of gcn/models.py:43-67."""
+        classes = {'c': GraphConvolution}
+        layer_type = []
+        for ch in self.model_config['connection']:
+            if ch not in classes:
+                raise ValueError('connection letter "%s": only graph convolutions ("c") are part of this build' % ch)
+            layer_type.append(classes[ch])
+        layer_size = copy(self.model_config['layer_size'])
+        layer_size.insert(0, self.input_dim)
+        layer_size.append(self.output_dim)
+        is_sparse = bool(getattr(self.placeholders['features'], 'sparse', False))
+        prev = self.inputs
+        for li, (output_dim, layer_cls, act) in enumerate(zip(layer_size[1:], layer_type, self.act)):
+            layer = layer_cls(input=prev, output_dim=output_dim, placeholders=self.placeholders, act=act,
+                              dropout=True, sparse_inputs=is_sparse, logging=self.logging,
+                              use_theta=self.model_config['conv'] == 'chebytheta',
+                              name='%s/graphconvolution_%d' % (self.name, li))
+            self.layers.append(layer)
+            is_sparse = False
+            prev = layer
+        for layer in self.layers:
+            for key, var in layer.vars.items():
+                self.vars[layer.name + '/' + key] = var
+        self.optimizer = TfAdam(self._trainable(), self.model_config['learning_rate'])
+
+    def _trainable(self):
+        return [var for layer in self.layers for var in layer.vars.values()]
+
+    # ------------------------------------------------------------------ #
+    def _bind(self, feed_dict):
+        """Put the fed values behind the placeholders, uploading each host object once."""
+        for ph in list(self.placeholders.values()):
+            for p in (ph if isinstance(ph, (list, tuple)) else [ph]):
+                if isinstance(p, graph.Placeholder):
+                    p.value = None
+        for ph, val in feed_dict.items():
+            if not isinstance(ph, graph.Placeholder):
+                raise TypeError('feed_dict keys must be placeholders')
+            ph.value = self._to_device(ph, val)
+
+    def _to_device(self, ph, val):
+        if ph.sparse:
+            if isinstance(val, sparse.DeviceCSR):
+                return val
+            csr = getattr(val, 'csr', None)
+            if csr is not None:
+                return csr
+            key = id(val)
+            hit = self._device_cache.get(key)
+            if hit is None or hit[0] is not val:
+                hit = (val, sparse.triple_to_device_csr(val))
+                self._device_cache[key] = hit
+            return hit[1]
+        if ph.name in ('dropout', 'num_features_nonzero'):
+            return val
+        if isinstance(val, torch.Tensor):
+            return val.cuda()
+        key = id(val)
+        hit = self._device_cache.get(key)
+        if hit is None or hit[0] is not val:
+            arr = np.asarray(val)
+            dtype = torch.int32 if ph.dtype == graph.int32 else torch.float32
+            hit = (val, torch.as_tensor(arr.astype(np.int32 if dtype == torch.int32 else np.float32)).cuda())
+            self._device_cache[key] = hit
+        return hit[1]
+
+    def _forward(self):
+        """gcn/models.py:54-69: every layer's dropout draws its own stream of this run."""
+        self.activations = [self.inputs.value]
+        hidden = self.inputs.value
+        for li, layer in enumerate(self.layers):
+            layer.stream_id = self._run_counter * 64 + li
+            hidden = layer(hidden)
+            self.activations.append(hidden)
+        return hidden
+
+    def _loss(self, outputs, labels, mask):
+        """gcn/models.py:92-99: weight decay on EVERY variable of EVERY layer + masked cross-entropy."""
+        loss = 0
+        for layer in self.layers:
+            for var in layer.vars.values():
+                loss = loss + self.model_config['weight_decay'] * (var * var).sum() / 2
+        return loss + masked_softmax_cross_entropy(outputs, labels, mask)
+
+    def _evaluate(self, keys, feed_dict):
+        self._bind(feed_dict)
+        self._run_counter += 1
+        labels = self.placeholders['labels'].value
+        mask = self.placeholders['labels_mask'].value
+        train = 'opt_op' in keys
+        out = {}
+        with torch.set_grad_enabled(train):
+            outputs = self._forward()
+            need_loss = train or 'loss' in keys
+            loss = self._loss(outputs, labels, mask) if need_loss else None
+            if train:
+                params = self._trainable()
+                grads = torch.autograd.grad(loss, params)
+                self.optimizer.step(grads)
+                self.global_step += 1
+                out['opt_op'] = None
+        with torch.no_grad():
+            if 'outputs' in keys:
+                out['outputs'] = graph.to_numpy(outputs)
+            if 'prediction' in keys:
+                out['prediction'] = graph.to_numpy(torch.softmax(outputs, dim=1))      # models.py:89-90
+            if 'loss' in keys:
+                out['loss'] = np.float32(loss.item())
+            if 'accuracy' in keys:
+                out['accuracy'] = np.float32(masked_accuracy(outputs, labels, mask).item())     # models.py:106-108
+            if 'accuracy_of_class' in keys:
+                m = mask.to(torch.float32)
+                out['accuracy_of_class'] = [
+                    np.float32(masked_accuracy(outputs, labels, m * labels[:, i].to(torch.float32)).item())
+                    for i in range(self.output_dim)]                                            # models.py:110-113
+            if 'summary' in keys:
+                out['summary'] = None
+        return out
+
+    # ------------------------------------------------------------------ #
+    def save(self, sess=None):
+        """Checkpointing of the reference (models.py:115-128) is never called by its driver; kept as a
+        plain state-dict dump for completeness of the interface."""
+        if not sess:
+            raise AttributeError('Session not provided.')
+        path = 'tmp/%s.pt' % self.name
+        torch.save({k: v.detach().cpu() for k, v in self.vars.items()}, path)
+        print('Model saved in file: %s' % path)
+
+    def load(self, sess=None):
+        if not sess:
+            raise AttributeError('Session not provided.')
+        path = 'tmp/%s.pt' % self.name
+        state = torch.load(path, weights_only=True)
+        with torch.no_grad():
+            for k, v in state.items():
+                self.vars[k].copy_(v)
+        print('Model restored from file: %s' % path)

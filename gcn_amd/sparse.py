@@ -233,6 +233,32 @@ def csr_transpose(a):
     return DeviceCSR(a.n_cols, a.n_rows, t_indptr, t_indices, t_vals, perm=perm)
 
 
+def triple_to_device_csr(triple, device='cuda'):
+    """Device CSR of a fed ``(indices [nnz,2], values, dense_shape)`` triple, values cast to
+    float32 as the float32 sparse placeholder does (train.py:145-146).  The order of the entries
+    inside every row is kept (it is the accumulation order of the reference's kernel); a triple
+    that is not row-grouped is stably regrouped by row first."""
+    import numpy as np
+    coords = np.asarray(triple[0])
+    values = np.asarray(triple[1])
+    n_rows, n_cols = (int(v) for v in triple[2])
+    if coords.ndim != 2 or coords.shape[1] != 2 or coords.shape[0] != values.shape[0]:
+        raise ValueError('a sparse triple needs indices [nnz, 2] and values [nnz]')
+    rows = coords[:, 0]
+    if rows.size and np.any(rows[1:] < rows[:-1]):
+        order = np.argsort(rows, kind='stable')
+        coords, values, rows = coords[order], values[order], rows[order]
+    if rows.size and (rows[0] < 0 or rows[-1] >= n_rows):
+        raise ValueError('a row index is outside [0, %d)' % n_rows)
+    d_rows = torch.as_tensor(np.ascontiguousarray(rows).astype(np.int32)).to(device)
+    indptr = rows_to_indptr(n_rows, d_rows)
+    csr = DeviceCSR(n_rows, n_cols, indptr,
+                    torch.as_tensor(np.ascontiguousarray(coords[:, 1]).astype(np.int32)).to(device),
+                    torch.as_tensor(values.astype(np.float32)).to(device))
+    csr.check_indices()
+    return csr
+
+
 # --------------------------------------------------------------------------- #
 # synthetic inputs
 # --------------------------------------------------------------------------- #

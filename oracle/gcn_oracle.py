@@ -374,14 +374,17 @@ class GcnOracle(object):
         self.feat_t = csr_transpose(n, f_in, *feat)       # for X'^T . G
 
     # -- forward ----------------------------------------------------------- #
-    def forward(self, dropout=0.0, seed=0, step=0):
-        """gcn/layers.py:178-214 per layer: dropout -> X.W -> A_hat. -> act (no bias)."""
+    def forward(self, dropout=0.0, seed=0, stream_ids=None):
+        """gcn/layers.py:178-214 per layer: dropout -> X.W -> A_hat. -> act (no bias).
+        ``stream_ids[li]`` names the random stream layer li's dropout draws from."""
         keep = np.float32(1.0) - np.float32(dropout)
+        if stream_ids is None:
+            stream_ids = list(range(len(self.w)))
         cache = {'keep': keep}
         ip, ix, xv = self.feat
         # layer 1: sparse inputs (models.py:50, 61)
         if dropout:
-            m, xs = sparse_dropout_values(xv, keep, stream_key(seed, 2 * step))
+            m, xs = sparse_dropout_values(xv, keep, stream_key(seed, stream_ids[0]))
             xs = np.where(m, xs, np.float32(0))
             # dropped entries are skipped, not added as zeros
             cache['xmask'] = m
@@ -398,7 +401,7 @@ class GcnOracle(object):
         for li in range(1, len(self.w)):
             h = np.maximum(h, np.float32(0))              # act of the previous layer (models.py:17)
             if dropout:
-                hd, hm = dense_dropout(h, keep, stream_key(seed, 2 * step + li))
+                hd, hm = dense_dropout(h, keep, stream_key(seed, stream_ids[li]))
             else:
                 hd, hm = h, None
             cache['hin'].append(hd)

@@ -156,7 +156,8 @@ def main():
     for name in ['cora', 'citeseer']:
         fx = dataset_fixture(utils, name)
         np.savez_compressed(os.path.join(out_dir, name + '.npz'), **fx)
-        np.savez_compressed(os.path.join(out_dir, name + '_raw.npz'), **raw_dataset(args.ref, name))
+        np.savez_compressed(os.path.join(os.path.dirname(out_dir), '..', 'data', name + '_raw.npz'),
+                            **raw_dataset(args.ref, name))
         print(name, 'n', int(fx['n']), 'nnz(A)', fx['adj_row'].size, 'nnz(hat)', fx['hat_values'].size,
               'nnz(X)', fx['feat_values'].size, fx['feat_values'].dtype)
 

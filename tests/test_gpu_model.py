@@ -1,0 +1,182 @@
+"""GPU parity of the layer / model / driver mirror (gcn/layers.py, gcn/models.py, train.py) against
+the CPU oracle on Cora and CiteSeer: logits, loss, accuracy, gradients, Adam steps, dropout masks.
+
+PARITY UNPINNED at the TensorFlow boundary (TensorFlow is not importable and the reference holds
+no golden vectors): the checker is the oracle's restatement of the cited lines.  Tolerance for
+float32 tensors: max|x - ref| <= 1e-5 * max|ref| (the sparse products themselves are bit-exact;
+the dense H.W product runs on the MFMA pipe in a different association order than numpy).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+
+
+def _close(a, b, tol=REL_TOL):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-30)
+
+
+def _setup(name, oracle, seed=5):
+    from gcn_amd import graph as tf, sparse
+    from gcn_amd.models import GCN_MLP
+    from gcn_amd.utils import SupportValue, construct_feed_dict
+    import scipy.sparse as sp
+    from gcn_amd.utils import preprocess_adj
+    fx = load_golden(name)
+    n = int(fx['n'])
+    adj = sp.csr_matrix((np.ones(fx['adj_row'].size), (fx['adj_row'], fx['adj_col'])), shape=(n, n))
+    support = [preprocess_adj(adj)]
+    features = SupportValue(fx['feat_coords'], fx['feat_values'], fx['feat_shape'])
+    y_train, train_mask = fx['y_train'].astype(np.float64), fx['train_mask']
+    tf.set_random_seed(seed)
+    placeholders = {
+        'support': [tf.sparse_placeholder(tf.float32, name='support0')],
+        'features': tf.sparse_placeholder(tf.float32, name='features'),
+        'labels': tf.placeholder(tf.int32, name='labels', shape=(None, y_train.shape[1])),
+        'labels_mask': tf.placeholder(tf.int32, name='labels_mask'),
+        'dropout': tf.placeholder_with_default(0., name='dropout', shape=()),
+        'num_features_nonzero': tf.placeholder(tf.int32, name='num_features_nonzero'),
+    }
+    cfg = {'name': 'gcn', 'connection': ['c', 'c'], 'layer_size': [16], 'conv': 'gcn', 'learning_rate': 0.02,
+           'weight_decay': 5e-4, 'Model': 'GCN', 'dropout': 0.5}
+    model = GCN_MLP(cfg, placeholders, input_dim=int(fx['feat_shape'][1]))
+    feed = construct_feed_dict(features, support, y_train, train_mask, placeholders)
+    ip, ix, v32, _ = oracle.triple_to_csr(fx['hat_indices'], fx['hat_values'], fx['hat_shape'])
+    feat = (fx['feat_indptr'].astype(np.int64), fx['feat_coords'][:, 1], fx['feat_values'].astype(np.float32))
+    weights = [w.detach().cpu().numpy().copy() for w in model._trainable()]
+    ref = oracle.GcnOracle((ip, ix, v32), feat, n, weights)
+    return fx, tf, model, placeholders, feed, ref, support
+
+
+@pytest.mark.parametrize('name', ['cora', 'citeseer'])
+def test_preprocess_adj_triple_and_device_csr(name, oracle):
+    """The drop-in preprocess_adj: triple as the reference returns it + the resident CSR."""
+    fx, tf, model, ph, feed, ref, support = _setup(name, oracle)
+    s = support[0]
+    indices, values, dense_shape = s                                   # callers unpack it (train.py:125)
+    assert indices.dtype == np.int32 and np.array_equal(indices, fx['hat_indices'])
+    assert np.array_equal(dense_shape, fx['hat_shape'])
+    assert np.abs(values.view(np.int64) - fx['hat_values'].view(np.int64)).max() <= 4      # float64 ulps
+    assert np.array_equal(s.csr.indptr.cpu().numpy(), fx['ai_indptr'])
+    assert np.array_equal(s.csr.indices.cpu().numpy(), fx['ai_indices'])
+    assert np.array_equal(s.csr.values.cpu().numpy(), fx['hat_values'].astype(np.float32))
+
+
+@pytest.mark.parametrize('name', ['cora', 'citeseer'])
+def test_forward_loss_accuracy_at_fixed_weights(name, oracle):
+    fx, tf, model, ph, feed, ref, _ = _setup(name, oracle)
+    sess = tf.Session()
+    outputs, loss, acc, acc_cls, pred = sess.run(
+        [model.outputs, model.loss, model.accuracy, model.accuracy_of_class, model.prediction], feed_dict=feed)
+    logits = ref.forward()
+    labels, mask = fx['y_train'], fx['train_mask']
+    assert _close(outputs, logits)
+    # layer 1 is sparse-only arithmetic: bit-exact
+    assert np.array_equal(model.activations[1].cpu().numpy(), np.maximum(ref.cache['z'][0], 0))
+    assert abs(float(loss) - float(ref.loss(logits, labels, mask))) <= 1e-5 * abs(float(loss))
+    assert abs(float(acc) - float(ref.masked_accuracy(logits, labels, mask))) <= 1e-6
+    for i, a in enumerate(acc_cls):
+        m = mask * labels[:, i]
+        assert abs(float(a) - float(ref.masked_accuracy(logits, labels, m))) <= 1e-6
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    assert _close(pred, e / e.sum(1, keepdims=True))
+    assert outputs.shape == (int(fx['n']), labels.shape[1])
+
+
+@pytest.mark.parametrize('name', ['cora', 'citeseer'])
+def test_gradients_and_adam_steps(name, oracle):
+    import torch
+    fx, tf, model, ph, feed, ref, _ = _setup(name, oracle)
+    labels, mask = fx['y_train'], fx['train_mask']
+    # raw gradients, dropout off
+    model._bind(feed)
+    with torch.enable_grad():
+        out = model._forward()
+        loss = model._loss(out, ph['labels'].value, ph['labels_mask'].value)
+        grads = torch.autograd.grad(loss, model._trainable())
+    logits = ref.forward()
+    ref_grads = ref.backward(logits, labels, mask)
+    for g, rg in zip(grads, ref_grads):
+        assert _close(g.cpu().numpy(), rg, 2e-5)
+    # three optimiser steps (TensorFlow's Adam form), dropout off
+    sess = tf.Session()
+    adam = oracle.TfAdam(ref.w, 0.02)
+    for _ in range(3):
+        sess.run(model.opt_op, feed_dict=feed)
+        lg = ref.forward()
+        adam.step(ref.w, ref.backward(lg, labels, mask))
+    # Adam divides by sqrt(v): where a gradient component passes through zero it turns float32
+    # rounding noise into an O(lr * 1e-3) difference, so ask 1e-5 of all but a few entries and
+    # 1e-3 of every entry.
+    for p, rw in zip(model._trainable(), ref.w):
+        d = np.abs(p.detach().cpu().numpy().astype(np.float64) - rw)
+        scale = np.abs(rw).max()
+        assert (d <= REL_TOL * scale).mean() >= 0.999
+        assert d.max() <= 1e-3 * scale
+
+
+def test_training_mode_uses_the_same_dropout_masks_as_the_oracle(oracle):
+    fx, tf, model, ph, feed, ref, _ = _setup('cora', oracle, seed=77)
+    feed = dict(feed)
+    feed[ph['dropout']] = 0.5
+    sess = tf.Session()
+    outputs, loss = sess.run([model.outputs, model.loss], feed_dict=feed)
+    run = model._run_counter
+    logits = ref.forward(dropout=0.5, seed=77, stream_ids=[run * 64 + 0, run * 64 + 1])
+    assert np.array_equal(model.activations[1].cpu().numpy(), np.maximum(ref.cache['z'][0], 0))
+    assert _close(outputs, logits)
+    # about half of X's entries were dropped, and a second run draws a different mask
+    assert 0.45 < ref.cache['xmask'].mean() < 0.55
+    outputs2 = sess.run(model.outputs, feed_dict=feed)
+    assert not np.array_equal(outputs, outputs2)
+    # evaluation feeds leave dropout at its default 0 (train.py:149, 182-183)
+    feed_eval = {k: v for k, v in feed.items() if k is not ph['dropout']}
+    a = sess.run(model.outputs, feed_dict=feed_eval)
+    b = sess.run(model.outputs, feed_dict=feed_eval)
+    assert np.array_equal(a, b)
+
+
+def test_short_training_trajectory_follows_the_oracle(oracle):
+    """Five epochs with dropout 0.5: identical masks (counter-based RNG) and the same Adam, so the
+    loss curve of the GPU model tracks the CPU oracle's."""
+    fx, tf, model, ph, feed, ref, _ = _setup('cora', oracle, seed=3)
+    labels, mask = fx['y_train'], fx['train_mask']
+    feed = dict(feed)
+    feed[ph['dropout']] = 0.5
+    sess = tf.Session()
+    adam = oracle.TfAdam(ref.w, 0.02)
+    for epoch in range(5):
+        sess.run(model.opt_op, feed_dict=feed)
+        run = model._run_counter
+        lg = ref.forward(dropout=0.5, seed=3, stream_ids=[run * 64, run * 64 + 1])
+        adam.step(ref.w, ref.backward(lg, labels, mask))
+        loss = sess.run(model.loss, feed_dict=feed)
+        run = model._run_counter
+        ref_loss = ref.loss(ref.forward(dropout=0.5, seed=3, stream_ids=[run * 64, run * 64 + 1]), labels, mask)
+        assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss)), (epoch, loss, ref_loss)
+
+
+@pytest.mark.parametrize('name,floor', [('cora', 0.72), ('citeseer', 0.60)])
+def test_driver_reaches_the_expected_accuracy(name, floor, capsys):
+    """train.train() end to end from the raw dataset files: 20 labels per class, 200 epochs, test on
+    the best-train-accuracy epoch.  Kipf-style GCNs reach ~0.80 / ~0.68 on these random splits."""
+    import train as driver
+    from config import load_configuration
+    from gcn_amd import graph as tf
+    configuration, args = load_configuration(['--dataset', name, '--train_size', '20'], echo=False)
+    driver.args = args
+    cfg = configuration['model_list'][0]
+    seed = 123
+    np.random.seed(seed)
+    tf.set_random_seed(seed)
+    with tf.Session() as sess:
+        test_acc, test_acc_of_class, prediction, seconds = driver.train(cfg, sess, seed)
+    assert floor <= float(test_acc) <= 1.0
+    assert prediction.shape[1] == len(test_acc_of_class)
+    assert np.allclose(prediction.sum(1), 1.0, atol=1e-5)
+    assert 'Optimization Finished!' in capsys.readouterr().out
