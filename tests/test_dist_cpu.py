@@ -1,0 +1,91 @@
+"""CPU, world_size 2 over gloo: the row-partitioned product (gcn_amd/dist.py) -- contiguous row
+blocks, all-gather of the dense operand, local product -- gives exactly the single-process rows.
+The HIP product cannot run here, so the test injects the CPU oracle as the local multiply; the
+partition, the collective and the buffer handling are the code under test."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+
+class _HostCSR(object):
+    """Stand-in with DeviceCSR's fields, for host tensors."""
+
+    def __init__(self, n_rows, n_cols, indptr, indices, values):
+        self.n_rows, self.n_cols = n_rows, n_cols
+        self.indptr, self.indices, self.values = indptr, indices, values
+        self.device = indptr.device
+
+    @property
+    def nnz(self):
+        return int(self.indices.numel())
+
+
+def _oracle_spmm(a, b, relu=False, out=None):
+    import gcn_oracle
+    c = gcn_oracle.spmm_csr(a.indptr.numpy(), a.indices.numpy(), a.values.numpy(), b.numpy(), relu=relu)
+    out.copy_(torch.from_numpy(c))
+    return out
+
+
+def _worker(rank, world, port, result_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from gcn_amd import dist as gdist, sparse
+        import gcn_oracle
+        fx = load_golden('cora')
+        n = int(fx['n'])
+        pad = (-n) % world                       # equal blocks: pad with empty rows / unused columns
+        n_pad = n + pad
+        indptr = np.concatenate([fx['ai_indptr'].astype(np.int64), np.full(pad, fx['ai_indptr'][-1], np.int64)])
+        full_indptr = torch.from_numpy(indptr)
+        indices = torch.from_numpy(fx['ai_indices'].astype(np.int32))
+        values = torch.from_numpy(fx['hat_values'].astype(np.float32))
+        r0, r1 = gdist.row_block(n_pad, rank, world)
+        k0, k1 = int(full_indptr[r0]), int(full_indptr[r1])
+        local = _HostCSR(r1 - r0, n_pad, full_indptr[r0:r1 + 1] - k0, indices[k0:k1].clone(), values[k0:k1].clone())
+        shard = gdist.RowShardedCSR(n_pad, n_pad, r0, r1, local, rank, world)
+        f = 16
+        b = np.zeros((n_pad, f), dtype=np.float32)
+        b[:n] = gcn_oracle.synthetic_dense(n, f, seed=13)
+        op = gdist.AllGatherSpmm(shard, f, spmm=_oracle_spmm)
+        c_local = op(torch.from_numpy(b[r0:r1].copy()), relu=True)
+        assert torch.equal(op.b_full, torch.from_numpy(b))             # the all-gather rebuilt B exactly
+        np.save(os.path.join(result_dir, 'c_%d.npy' % rank), c_local.numpy())
+        # the MAX-over-ranks timing reduction bench.py uses
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t) == float(world)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_row_sharded_product_equals_single_process(world, oracle, tmp_path):
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    fx = load_golden('cora')
+    n = int(fx['n'])
+    b = oracle.synthetic_dense(n, 16, seed=13)
+    ref = oracle.spmm_csr(fx['ai_indptr'].astype(np.int64), fx['ai_indices'], fx['hat_values'].astype(np.float32), b,
+                          relu=True)
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), 'c_%d.npy' % r)) for r in range(world)])[:n]
+    assert np.array_equal(got, ref)          # same per-row order on every rank: bit-identical
+
+
+def test_row_block_requires_equal_blocks():
+    sys.path.insert(0, ROOT)
+    from gcn_amd import dist as gdist
+    assert gdist.row_block(8, 1, 4) == (2, 4)
+    with pytest.raises(ValueError):
+        gdist.row_block(10, 0, 4)
