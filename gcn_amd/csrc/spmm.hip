@@ -2,13 +2,16 @@
 // sparse dropout (gcn/layers.py:19-25, 198-199).  HBM-bound gather kernels for gfx950.
 //
 // Work decomposition
-//   strips : the nnz axis is cut every kStripNnz entries; a wave owns the rows that START inside its
-//            strip, so waves carry equal work however skewed the degrees are.  Inside a wave, groups
-//            of LPR lanes own one row each; a lane holds VPL vectors of VEC floats of that row.
-//   chunks : rows longer than kSplitNnz are left out of the strips, cut in chunks of kSplitNnz
-//            entries, each chunk summed by one lane group into a partial row, and the partial rows
-//            of a row are added in chunk order by a third kernel.
-// Every row of at most kSplitNnz entries is therefore accumulated sequentially in storage order with
+//   strips : the nnz axis is cut every kStripNnz entries; the rows that START inside a strip belong to
+//            it, so strips carry equal work however skewed the degrees are.  A lane group of LPR lanes
+//            owns one row at a time; a lane holds VPL vectors of VEC floats of that row.  Wide rows
+//            (LPR = 64): one wave per strip, rows one after the other.  Narrow rows (LPR < 64): a
+//            wave takes 64/LPR consecutive strips and its lane groups pull the next row of that
+//            range whenever they finish one, so no group idles behind a longer neighbour.
+//   chunks : rows longer than the split threshold (256 entries for narrow operands, 1024 for wide
+//            ones) are left out of the strips, cut in chunks of that many entries, each chunk summed by one lane group into a partial row, and the partial rows
+//            of a row are added in chunk order by a second kernel.
+// Every row of at most 256 entries is therefore accumulated sequentially in storage order with
 // a separate multiply and add (this file is compiled with -ffp-contract=off): bit-identical to the
 // serial CPU loop.
 #include <algorithm>
@@ -18,12 +21,17 @@
 
 struct gcn_spmm_plan {
     int64_t n_rows, n_cols, nnz;
-    int64_t n_strips, n_long, n_chunks;
+    int64_t n_strips;
     int device;
-    int32_t* strip_row;   // [n_strips + 1] first row starting in each strip
-    int32_t* long_row;    // [n_long] rows longer than kSplitNnz, ascending
-    int64_t* long_chunk;  // [n_long + 1] first chunk of each long row
-    int32_t* chunk_long;  // [n_chunks] long-row slot of each chunk
+    int32_t* strip_row;  // [n_strips + 1] first row starting in each strip
+    // rows longer than the split threshold, cut in chunks of that many entries; table 0 serves narrow
+    // dense operands (threshold kSplitNarrow), table 1 wide ones (kSplitWide)
+    struct LongTable {
+        int64_t n_long, n_chunks;
+        int32_t* long_row;    // [n_long] ascending
+        int64_t* long_chunk;  // [n_long + 1] first chunk of each long row
+        int32_t* chunk_long;  // [n_chunks] long-row slot of each chunk
+    } table[2];
     int timing;           // record events around the kernels of every product
     hipEvent_t ev[3];     // start, after the row kernel, after the long-row reduction
 };
@@ -31,7 +39,9 @@ struct gcn_spmm_plan {
 namespace gcn {
 
 constexpr int kStripNnz = 256;
-constexpr int kSplitNnz = 1024;
+constexpr int kSplitNarrow = 256;   // lane groups narrower than a wave: every work item <= 256 entries
+constexpr int kSplitWide = 1024;    // one wave per row
+static inline int split_of(int table) { return table == 0 ? kSplitNarrow : kSplitWide; }
 constexpr int kBlock = 256;
 constexpr int kUnroll = 4;
 
@@ -58,13 +68,13 @@ __global__ void strip_rows_kernel(int64_t n_rows, const int64_t* __restrict__ in
     strip_row[w] = (int32_t)lo;
 }
 
-__global__ void collect_long_rows_kernel(int64_t n_rows, const int64_t* __restrict__ indptr, int64_t capacity,
+__global__ void collect_long_rows_kernel(int64_t n_rows, const int64_t* __restrict__ indptr, int split, int64_t capacity,
                                          int32_t* __restrict__ rows, int64_t* __restrict__ starts,
                                          int64_t* __restrict__ ends, unsigned long long* __restrict__ counter) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const int64_t k0 = indptr[r], k1 = indptr[r + 1];
-    if (k1 - k0 > kSplitNnz) {
+    if (k1 - k0 > split) {
         const unsigned long long slot = atomicAdd(counter, 1ull);
         if ((int64_t)slot < capacity) {
             rows[slot] = (int32_t)r;
@@ -204,7 +214,7 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                              uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
-                                             const DropArgs& dr) {
+                                             const DropArgs& dr, int split) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;  // columns covered per pass
     const int lane = threadIdx.x & 63;
@@ -227,7 +237,7 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
         for (int r = r_lo + grp; r < r_hi; r += kGroups) {
             const int64_t k0 = indptr[r];
             const int64_t k1 = indptr[r + 1];
-            if (k1 - k0 > kSplitNnz) continue;  // summed chunk-wise
+            if (k1 - k0 > split) continue;  // summed chunk-wise
             float acc[VPL][VEC];
 #pragma unroll
             for (int v = 0; v < VPL; ++v)
@@ -239,6 +249,116 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
     }
 }
 
+// rows of ordinary length, narrow dense operand: a wave owns 64/LPR consecutive strips; each lane
+// group takes the next unclaimed row of that range when it has finished its own
+template <int LPR, int VEC, int VPL, bool DROPOUT>
+__device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, const int32_t* __restrict__ strip_row,
+                                            const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                            const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
+                                            uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
+                                            const DropArgs& dr, int split) {
+    constexpr int kGroups = 64 / LPR;
+    constexpr int kTile = LPR * VEC * VPL;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int64_t wave = block * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t s0 = wave * kGroups;
+    if (s0 >= n_strips) return;
+    const int64_t s1 = (s0 + kGroups < n_strips) ? s0 + kGroups : n_strips;
+    const int r_lo = strip_row[s0];
+    const int r_hi = strip_row[s1];
+    uint64_t leaders = 0;  // lane 0 of every group
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) leaders |= 1ull << (g * LPR);
+    const uint64_t below = leaders & ((1ull << (grp * LPR)) - 1ull);  // leaders of the groups before mine
+    for (int64_t col0 = 0; col0 < f; col0 += kTile) {
+        int col[VPL];
+        int lcol[VPL];
+        bool on[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            col[v] = (int)col0 + (v * LPR + sub) * VEC;
+            on[v] = col[v] < f;
+            lcol[v] = on[v] ? col[v] : (int)f - VEC;
+        }
+        int r_next = r_lo;  // first unclaimed row (same in every lane)
+        int r = -1;         // row this group is summing; -1: none
+        int64_t k = 0, k1 = 0;
+        bool live = true;  // the range may still hold a row for this group
+        float acc[VPL][VEC];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
+        for (;;) {
+            const bool idle = live && (k >= k1);
+            const uint64_t m = __ballot(idle) & leaders;
+            if (idle) {
+                if (r >= 0) store_row<VEC, VPL>(c + (int64_t)r * ldc, col, on, acc, relu != 0);
+                const int rn = r_next + __popcll(m & below);
+                r = -1;
+                k = 0;
+                k1 = 0;
+                if (rn < r_hi) {
+                    const int64_t a0 = indptr[rn];
+                    const int64_t a1 = indptr[rn + 1];
+                    if (a1 - a0 <= split) {  // longer rows are summed chunk-wise
+                        r = rn;
+                        k = a0;
+                        k1 = a1;
+                    }
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
+                } else {
+                    live = false;
+                }
+            }
+            r_next += __popcll(m);
+            if (__ballot(live) == 0) break;
+            if (k < k1) {
+                const int64_t k_last = k1 - 1;
+                const int64_t rem = k1 - k;
+                uint32_t cidx[kUnroll];
+                float a[kUnroll];
+                bool kept[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int64_t ku = (k + u < k_last) ? k + u : k_last;
+                    cidx[u] = (uint32_t)indices[ku];
+                    a[u] = vals[ku];
+                    kept[u] = true;
+                    if (DROPOUT) {
+                        const uint64_t id = dr.perm ? (uint64_t)dr.perm[ku] : (uint64_t)ku;
+                        kept[u] = keep_entry(dr.key, id, dr.keep_prob);
+                        a[u] = __fmul_rn(a[u], dr.inv_keep);
+                    }
+                }
+                float bv[kUnroll][VPL][VEC];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const float* brow = b + (uint64_t)cidx[u] * (uint64_t)ldb;
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) load_vec<VEC>(brow + lcol[v], bv[u][v]);
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    if (u < rem && kept[u]) {
+#pragma unroll
+                        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e)
+                                acc[v][e] = __fadd_rn(acc[v][e], __fmul_rn(a[u], bv[u][v][e]));
+                    }
+                }
+                k += kUnroll;
+            }
+        }
+    }
+}
+
 // one lane group per chunk of a long row -> partial row in the workspace
 template <int LPR, int VEC, int VPL, bool DROPOUT>
 __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, const int32_t* __restrict__ chunk_long,
@@ -246,7 +366,8 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
                                              const int64_t* __restrict__ long_chunk,
                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
-                                             uint32_t ldb, float* __restrict__ part, int64_t ldp, const DropArgs& dr) {
+                                             uint32_t ldb, float* __restrict__ part, int64_t ldp, const DropArgs& dr,
+                                             int split) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
@@ -257,9 +378,9 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
     if (chunk >= n_chunks) return;
     const int li = chunk_long[chunk];
     const int r = long_row[li];
-    const int64_t k0 = indptr[r] + (chunk - long_chunk[li]) * (int64_t)kSplitNnz;
+    const int64_t k0 = indptr[r] + (chunk - long_chunk[li]) * (int64_t)split;
     const int64_t row_end = indptr[r + 1];
-    const int64_t k1 = (k0 + kSplitNnz < row_end) ? k0 + kSplitNnz : row_end;
+    const int64_t k1 = (k0 + split < row_end) ? k0 + split : row_end;
     for (int64_t col0 = 0; col0 < f; col0 += kTile) {
         int col[VPL];
         int lcol[VPL];
@@ -282,6 +403,7 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
 
 struct PlanView {
     int64_t n_strips, n_chunks, chunk_blocks;
+    int split;
     const int32_t* strip_row;
     const int32_t* chunk_long;
     const int32_t* long_row;
@@ -301,27 +423,59 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
     const int64_t block = blockIdx.x;
     if (block < pv.chunk_blocks)
         chunks_block<LPR, VEC, VPL, DROPOUT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
-                                             indices, vals, f, b, ldb, part, ldp, dr);
-    else
+                                             indices, vals, f, b, ldb, part, ldp, dr, pv.split);
+    else if (LPR >= 32)
         strips_block<LPR, VEC, VPL, DROPOUT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
-                                             vals, f, b, ldb, c, ldc, relu, dr);
+                                             vals, f, b, ldb, c, ldc, relu, dr, pv.split);
+    else
+        slots_block<LPR, VEC, VPL, DROPOUT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
+                                            vals, f, b, ldb, c, ldc, relu, dr, pv.split);
 }
 
-// partial rows of each long row, added in chunk order; one wave per long row
+// partial rows of each long row, added in chunk order; one wave per long row.  Partial rows are
+// 16-byte aligned with a leading dimension that is a multiple of 4, so they are always read as
+// float4, eight chunks in flight; C is written as float4 only when `vec_c` says its layout allows it.
 __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(int64_t n_long, const int32_t* __restrict__ long_row,
                                                                   const int64_t* __restrict__ long_chunk, int64_t f,
                                                                   const float* __restrict__ part, int64_t ldp,
-                                                                  float* __restrict__ c, int64_t ldc, int relu) {
+                                                                  float* __restrict__ c, int64_t ldc, int relu,
+                                                                  int vec_c) {
+    constexpr int kDepth = 8;
     const int lane = threadIdx.x & 63;
     const int64_t li = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (li >= n_long) return;
     const int64_t c0 = long_chunk[li], c1 = long_chunk[li + 1];
     float* dst = c + (int64_t)long_row[li] * ldc;
-    for (int64_t j = lane; j < f; j += 64) {
-        float s = 0.0f;
-        for (int64_t ch = c0; ch < c1; ++ch) s = __fadd_rn(s, part[ch * ldp + j]);
-        if (relu) s = s > 0.0f ? s : 0.0f;
-        dst[j] = s;
+    for (int64_t j = (int64_t)lane * 4; j < f; j += 256) {
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* src = part + j;
+        int64_t ch = c0;
+        for (; ch + kDepth <= c1; ch += kDepth) {
+            float x[kDepth][4];
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) load_vec<4>(src + (ch + u) * ldp, x[u]);
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], x[u][e]);
+        }
+        for (; ch < c1; ++ch) {
+            float x[4];
+            load_vec<4>(src + ch * ldp, x);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], x[e]);
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.0f ? s[e] : 0.0f;
+        }
+        if (vec_c) {
+            store_vec<4>(dst + j, s);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j + e < f) dst[j + e] = s[e];
+        }
     }
 }
 
@@ -350,25 +504,29 @@ static int launch_variant(const SpmmCall& a) {
     const gcn_spmm_plan* p = a.plan;
     constexpr int kWaves = kBlock / 64;
     constexpr int kGroups = 64 / LPR;
+    const int ti = (LPR >= 32) ? 1 : 0;
+    const gcn_spmm_plan::LongTable& lt = p->table[ti];
     PlanView pv;
     pv.n_strips = p->n_strips;
-    pv.n_chunks = p->n_chunks;
-    pv.chunk_blocks = ceil_div(ceil_div(p->n_chunks, kGroups), kWaves);
+    pv.n_chunks = lt.n_chunks;
+    pv.chunk_blocks = ceil_div(ceil_div(lt.n_chunks, kGroups), kWaves);
+    pv.split = split_of(ti);
     pv.strip_row = p->strip_row;
-    pv.chunk_long = p->chunk_long;
-    pv.long_row = p->long_row;
-    pv.long_chunk = p->long_chunk;
-    const int64_t grid = pv.chunk_blocks + ceil_div(p->n_strips, kWaves);
+    pv.chunk_long = lt.chunk_long;
+    pv.long_row = lt.long_row;
+    pv.long_chunk = lt.long_chunk;
+    const int64_t strip_waves = (LPR >= 32) ? p->n_strips : ceil_div(p->n_strips, kGroups);
+    const int64_t grid = pv.chunk_blocks + ceil_div(strip_waves, kWaves);
     if (grid > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[0], a.st));
     spmm_rows_kernel<LPR, VEC, VPL, DROPOUT><<<(unsigned)grid, kBlock, 0, a.st>>>(
         pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr);
     GCN_LAUNCH_CHECK();
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[1], a.st));
-    if (p->n_chunks > 0) {
-        const unsigned grid2 = (unsigned)ceil_div(p->n_long, kWaves);
-        spmm_long_reduce_kernel<<<grid2, kBlock, 0, a.st>>>(p->n_long, p->long_row, p->long_chunk, a.f, a.part,
-                                                            a.ldp, a.c, a.ldc, a.relu);
+    if (lt.n_chunks > 0) {
+        const unsigned grid2 = (unsigned)ceil_div(lt.n_long, kWaves);
+        spmm_long_reduce_kernel<<<grid2, kBlock, 0, a.st>>>(lt.n_long, lt.long_row, lt.long_chunk, a.f, a.part,
+                                                            a.ldp, a.c, a.ldc, a.relu, VEC == 4 ? 1 : 0);
         GCN_LAUNCH_CHECK();
     }
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[2], a.st));
@@ -418,8 +576,9 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
     a.ldp = partial_ld(f);
     a.dr = dr;
     a.st = (hipStream_t)stream;
-    if (plan->n_chunks > 0) {
-        const size_t need = (size_t)plan->n_chunks * (size_t)a.ldp * sizeof(float);
+    const int64_t max_chunks = std::max(plan->table[0].n_chunks, plan->table[1].n_chunks);
+    if (max_chunks > 0) {
+        const size_t need = (size_t)max_chunks * (size_t)a.ldp * sizeof(float);
         if (!workspace || workspace_bytes < need)
             return fail(GCN_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
         if (!aligned16(workspace)) return fail(GCN_ERR_BAD_ARG, "workspace must be 16-byte aligned");
@@ -450,11 +609,13 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
     p->n_cols = n_cols;
     p->nnz = nnz;
     p->n_strips = std::max<int64_t>(1, ceil_div(nnz, kStripNnz));
-    p->n_long = p->n_chunks = 0;
     p->strip_row = nullptr;
-    p->long_row = nullptr;
-    p->long_chunk = nullptr;
-    p->chunk_long = nullptr;
+    for (int t = 0; t < 2; ++t) {
+        p->table[t].n_long = p->table[t].n_chunks = 0;
+        p->table[t].long_row = nullptr;
+        p->table[t].long_chunk = nullptr;
+        p->table[t].chunk_long = nullptr;
+    }
     p->timing = 0;
     p->ev[0] = p->ev[1] = p->ev[2] = nullptr;
     int32_t* d_rows = nullptr;
@@ -482,16 +643,17 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
     strip_rows_kernel<<<(unsigned)ceil_div(p->n_strips + 1, kBlock), kBlock, 0, st>>>(n_rows, indptr, p->n_strips,
                                                                                       p->strip_row);
     PLAN_TRY(hipGetLastError());
-    // rows longer than the split threshold (at most nnz / (kSplitNnz + 1) of them)
-    const int64_t cap = nnz / (kSplitNnz + 1);
+    // rows longer than the smaller split threshold (at most nnz / (kSplitNarrow + 1) of them); the table
+    // for the larger threshold is the subset of the same list
+    const int64_t cap = nnz / (kSplitNarrow + 1);
     if (cap > 0 && n_rows > 0) {
         PLAN_TRY(hipMalloc(&d_rows, (size_t)cap * sizeof(int32_t)));
         PLAN_TRY(hipMalloc(&d_starts, (size_t)cap * sizeof(int64_t)));
         PLAN_TRY(hipMalloc(&d_ends, (size_t)cap * sizeof(int64_t)));
         PLAN_TRY(hipMalloc(&d_count, sizeof(unsigned long long)));
         PLAN_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
-        collect_long_rows_kernel<<<(unsigned)ceil_div(n_rows, kBlock), kBlock, 0, st>>>(n_rows, indptr, cap, d_rows,
-                                                                                        d_starts, d_ends, d_count);
+        collect_long_rows_kernel<<<(unsigned)ceil_div(n_rows, kBlock), kBlock, 0, st>>>(
+            n_rows, indptr, kSplitNarrow, cap, d_rows, d_starts, d_ends, d_count);
         PLAN_TRY(hipGetLastError());
         unsigned long long count = 0;
         PLAN_TRY(hipMemcpyAsync(&count, d_count, sizeof(count), hipMemcpyDeviceToHost, st));
@@ -510,27 +672,37 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
             std::vector<int64_t> order(count);
             for (size_t i = 0; i < count; ++i) order[i] = (int64_t)i;
             std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return rows[x] < rows[y]; });
-            std::vector<int32_t> long_row(count);
-            std::vector<int64_t> long_chunk(count + 1);
-            std::vector<int32_t> chunk_long;
-            int64_t total = 0;
-            for (size_t i = 0; i < count; ++i) {
-                const int64_t o = order[i];
-                long_row[i] = rows[o];
-                long_chunk[i] = total;
-                const int64_t nch = ceil_div(ends[o] - starts[o], kSplitNnz);
-                for (int64_t j = 0; j < nch; ++j) chunk_long.push_back((int32_t)i);
-                total += nch;
+            for (int t = 0; t < 2; ++t) {
+                const int64_t split = split_of(t);
+                std::vector<int32_t> long_row;
+                std::vector<int64_t> long_chunk;
+                std::vector<int32_t> chunk_long;
+                int64_t total = 0;
+                for (size_t i = 0; i < count; ++i) {
+                    const int64_t o = order[i];
+                    const int64_t len = ends[o] - starts[o];
+                    if (len <= split) continue;
+                    const int32_t slot = (int32_t)long_row.size();
+                    long_row.push_back(rows[o]);
+                    long_chunk.push_back(total);
+                    const int64_t nch = ceil_div(len, split);
+                    chunk_long.insert(chunk_long.end(), (size_t)nch, slot);
+                    total += nch;
+                }
+                long_chunk.push_back(total);
+                const size_t nl = long_row.size();
+                if (nl == 0) continue;
+                gcn_spmm_plan::LongTable& lt = p->table[t];
+                lt.n_long = (int64_t)nl;
+                lt.n_chunks = total;
+                PLAN_TRY(hipMalloc(&lt.long_row, nl * sizeof(int32_t)));
+                PLAN_TRY(hipMalloc(&lt.long_chunk, (nl + 1) * sizeof(int64_t)));
+                PLAN_TRY(hipMalloc(&lt.chunk_long, (size_t)total * sizeof(int32_t)));
+                PLAN_TRY(hipMemcpy(lt.long_row, long_row.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice));
+                PLAN_TRY(hipMemcpy(lt.long_chunk, long_chunk.data(), (nl + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+                PLAN_TRY(hipMemcpy(lt.chunk_long, chunk_long.data(), (size_t)total * sizeof(int32_t),
+                                   hipMemcpyHostToDevice));
             }
-            long_chunk[count] = total;
-            p->n_long = (int64_t)count;
-            p->n_chunks = total;
-            PLAN_TRY(hipMalloc(&p->long_row, count * sizeof(int32_t)));
-            PLAN_TRY(hipMalloc(&p->long_chunk, (count + 1) * sizeof(int64_t)));
-            PLAN_TRY(hipMalloc(&p->chunk_long, (size_t)total * sizeof(int32_t)));
-            PLAN_TRY(hipMemcpy(p->long_row, long_row.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
-            PLAN_TRY(hipMemcpy(p->long_chunk, long_chunk.data(), (count + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-            PLAN_TRY(hipMemcpy(p->chunk_long, chunk_long.data(), (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice));
         }
     }
     PLAN_TRY(hipStreamSynchronize(st));
@@ -543,9 +715,11 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
 int gcn_spmm_plan_destroy(gcn_spmm_plan* plan) {
     if (!plan) return GCN_OK;
     (void)hipFree(plan->strip_row);
-    (void)hipFree(plan->long_row);
-    (void)hipFree(plan->long_chunk);
-    (void)hipFree(plan->chunk_long);
+    for (int t = 0; t < 2; ++t) {
+        (void)hipFree(plan->table[t].long_row);
+        (void)hipFree(plan->table[t].long_chunk);
+        (void)hipFree(plan->table[t].chunk_long);
+    }
     for (int i = 0; i < 3; ++i)
         if (plan->ev[i]) (void)hipEventDestroy(plan->ev[i]);
     delete plan;
@@ -572,15 +746,16 @@ int gcn_spmm_plan_last_timing(const gcn_spmm_plan* plan, float* ms2) {
 int gcn_spmm_plan_info(const gcn_spmm_plan* plan, int64_t* what4) {
     if (!plan || !what4) return fail(GCN_ERR_BAD_ARG, "null argument");
     what4[0] = plan->n_strips;
-    what4[1] = plan->n_long;
-    what4[2] = plan->n_chunks;
-    what4[3] = kSplitNnz;
+    what4[1] = plan->table[0].n_long;
+    what4[2] = plan->table[0].n_chunks;
+    what4[3] = kSplitNarrow;
     return GCN_OK;
 }
 
 int gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan* plan, int64_t f, size_t* workspace_bytes) {
     if (!plan || !workspace_bytes || f < 0) return fail(GCN_ERR_BAD_ARG, "bad argument");
-    *workspace_bytes = (size_t)plan->n_chunks * (size_t)partial_ld(f) * sizeof(float);
+    const int64_t max_chunks = std::max(plan->table[0].n_chunks, plan->table[1].n_chunks);
+    *workspace_bytes = (size_t)max_chunks * (size_t)partial_ld(f) * sizeof(float);
     return GCN_OK;
 }
 

@@ -132,7 +132,8 @@ typedef struct gcn_spmm_plan gcn_spmm_plan;
 int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, gcn_spmm_plan** plan_out,
                          void* stream);
 int gcn_spmm_plan_destroy(gcn_spmm_plan* plan);
-/* host-side facts about a plan: what[0]=n_strips, [1]=n_long_rows, [2]=n_chunks, [3]=split threshold */
+/* host-side facts about a plan: what[0]=n_strips, [1]=rows longer than the split threshold, [2]=their
+ * chunks, [3]=the split threshold (the smallest one: rows up to it are summed serially for every width) */
 int gcn_spmm_plan_info(const gcn_spmm_plan* plan, int64_t* what4);
 int gcn_spmm_plan_workspace_bytes(const gcn_spmm_plan* plan, int64_t f, size_t* workspace_bytes);
 /* Measurement hook (the reference times its step with time.time(), train.py:203-205): when enabled,
@@ -145,8 +146,8 @@ int gcn_spmm_plan_last_timing(const gcn_spmm_plan* plan, float* ms2);
 /* C[n_rows x f] = A . B, A in CSR, B [n_cols x f]: `dot(x, y, sparse=True)`
  * = tf.sparse_tensor_dense_matmul at gcn/layers.py:28-31, called at
  * layers.py:202 (A_hat . (XW)) and layers.py:198-199 (X . W0).  Every output row
- * of at most `split threshold` nonzeros is accumulated sequentially in storage
- * order with a separate float32 multiply and add (the order of the serial
+ * of at most `split threshold` (256) nonzeros is accumulated sequentially in
+ * storage order with a separate float32 multiply and add (the order of the serial
  * CPU loop); longer rows are summed in fixed-size chunks, then chunk by chunk. */
 int gcn_spmm_csr_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
                      int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
