@@ -37,6 +37,10 @@ def parse_args():
     ap.add_argument('--edge-factor', type=int, default=16)
     ap.add_argument('--features', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--allgather', action='store_true',
+                    help='N > 1: all-gather the whole of B instead of exchanging only the referenced rows')
+    ap.add_argument('--rehearse-on-one-gpu', action='store_true',
+                    help='development only: every rank uses cuda:0 and the gloo backend')
     ap.add_argument('--cpu-row-stride', type=int, default=64,
                     help='the CPU baseline multiplies every k-th row of the same matrix')
     return ap.parse_args()
@@ -119,11 +123,16 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from gcn_amd import sparse, dist as gdist
 
@@ -146,8 +155,8 @@ def main():
         b_local = b_full[shard.row_begin:shard.row_end].clone()
         del b_full
         torch.cuda.empty_cache()
-        op = gdist.AllGatherSpmm(shard, f)
-        a = shard.local
+        op = gdist.HaloSpmm(shard, f) if not args.allgather else gdist.AllGatherSpmm(shard, f)
+        a = op.compact if not args.allgather else shard.local
         a.plan.set_timing(True)
 
         def step():
@@ -190,7 +199,7 @@ def main():
             'config': {'workload': 'A_hat.B, R-MAT scale %d edge factor %d (+I, sym-normalised), F=%d'
                                    % (args.scale, args.edge_factor, f),
                        'n_nodes': n, 'nnz': nnz, 'features': f,
-                       'parallelism': 'rows/%d + all-gather(B)' % world if world > 1 else 'single GPU'},
+                       'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B')) if world > 1 else 'single GPU'},
             'pct_of_hbm_peak': 100.0 * value / (HBM_PEAK_GBPS * world),
             'gather_gbps': total_gather / (ms_per_step * 1e-3) / 1e9,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

@@ -62,6 +62,12 @@ def _worker(rank, world, port, result_dir):
         c_local = op(torch.from_numpy(b[r0:r1].copy()), relu=True)
         assert torch.equal(op.b_full, torch.from_numpy(b))             # the all-gather rebuilt B exactly
         np.save(os.path.join(result_dir, 'c_%d.npy' % rank), c_local.numpy())
+        # the exchange that ships only the referenced rows of B gives the same bits
+        halo = gdist.HaloSpmm(shard, f, spmm=_oracle_spmm, csr_factory=_HostCSR)
+        c_halo = halo(torch.from_numpy(b[r0:r1].copy()), relu=True)
+        assert torch.equal(c_halo, c_local)
+        assert halo.n_needed <= n_pad and sum(halo.recv_splits) == halo.n_needed
+        np.save(os.path.join(result_dir, 'needed_%d.npy' % rank), np.array([halo.n_needed]))
         # the MAX-over-ranks timing reduction bench.py uses
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -81,6 +87,8 @@ def test_row_sharded_product_equals_single_process(world, oracle, tmp_path):
                           relu=True)
     got = np.concatenate([np.load(os.path.join(str(tmp_path), 'c_%d.npy' % r)) for r in range(world)])[:n]
     assert np.array_equal(got, ref)          # same per-row order on every rank: bit-identical
+    for r in range(world):                   # a shard references only part of the columns
+        assert int(np.load(os.path.join(str(tmp_path), 'needed_%d.npy' % r))[0]) < n
 
 
 def test_row_block_requires_equal_blocks():
