@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument('--edge-factor', type=int, default=16)
     ap.add_argument('--features', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-epoch', action='store_true', help='skip the Planetoid epoch-time leg')
     ap.add_argument('--allgather', action='store_true',
                     help='N > 1: all-gather the whole of B instead of exchanging only the referenced rows')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
@@ -66,6 +67,41 @@ def build_graph(scale, edge_factor):
     del deg, d
     torch.cuda.empty_cache()
     return indptr, indices, vals
+
+
+def measured_traffic(kernel, scale, edge_factor, f, world):
+    """HBM-side bytes per launch of the row kernel from the rocprofv3 PMC passes kept under profiles/
+    (FETCH_SIZE and WRITE_SIZE cannot share a pass, so they come from separate runs of this same
+    command; corrected as (2 * FETCH_SIZE + WRITE_SIZE) * 1024).  None when no record matches."""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        for rec in json.load(fh):
+            if (rec['kernel'], rec['scale'], rec['edge_factor'], rec['features']) == (kernel, scale, edge_factor, f):
+                return rec['hbm_bytes_per_launch']
+    return None
+
+
+def planetoid_epoch_ms(name, epochs=60):
+    """Median wall time of one optimiser step (forward + backward + Adam: the region the reference
+    times at train.py:203-205) of the 2-layer GCN on a Planetoid dataset, 20 labels per class."""
+    import contextlib
+    import io
+    import train as driver
+    from config import load_configuration
+    from gcn_amd import graph as tf
+    configuration, args = load_configuration(['--dataset', name, '--train_size', '20'], echo=False)
+    driver.args = args
+    cfg = configuration['model_list'][0]
+    cfg['epochs'] = epochs
+    np.random.seed(123)
+    tf.set_random_seed(123)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), tf.Session() as sess:
+        test_acc, _, _, _ = driver.train(cfg, sess, 123)
+    ms = [float(line.split('median')[1].split()[0]) for line in buf.getvalue().splitlines() if 'epoch ms' in line]
+    return {'dataset': name, 'epoch_ms': ms[0] if ms else None, 'epochs': epochs, 'test_acc': float(test_acc)}
 
 
 def cpu_baseline(a, b_dev, c_dev, row_stride):
@@ -203,7 +239,8 @@ def main():
             'pct_of_hbm_peak': 100.0 * value / (HBM_PEAK_GBPS * world),
             'gather_gbps': total_gather / (ms_per_step * 1e-3) / 1e9,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBPS,
+                         'traffic': measured_traffic('spmm_rows_kernel', args.scale, args.edge_factor, f, world),
                          'kernel': 'spmm_rows_kernel', 'kernel_ms': row_ms, 'reduce_kernel_ms': red_ms,
                          'algorithmic_bytes': local_min},
         }
@@ -212,6 +249,11 @@ def main():
             line['cpu_baseline'] = base
             line['cpu_baseline_all_cores'] = allcores
             line['parity_sample'] = check
+        if world == 1 and not args.no_epoch:
+            line['gcn_epoch'] = [planetoid_epoch_ms('cora'), planetoid_epoch_ms('citeseer')]
+        t = line['roofline']['traffic']
+        if t:
+            line['hbm_measured_gbps'] = t / (row_ms * 1e-3) / 1e9
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()
