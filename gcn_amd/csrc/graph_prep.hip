@@ -236,6 +236,20 @@ __global__ void degree_scale_kernel(int64_t n, const double* __restrict__ rowsum
     }
 }
 
+// bag-of-words row scaling: one thread per row, sum and scale in storage order
+template <typename T>
+__global__ void row_normalize_kernel(int64_t n_rows, const int64_t* __restrict__ indptr, const T* __restrict__ vals,
+                                     T* __restrict__ out) {
+    GCN_GRID_STRIDE(r, n_rows) {
+        const int64_t k0 = indptr[r], k1 = indptr[r + 1];
+        T s = (T)0;
+        for (int64_t k = k0; k < k1; ++k) s += vals[k];
+        T inv = (T)1 / s;  // np.power(rowsum, -1)
+        if (isinf(inv)) inv = (T)0;
+        for (int64_t k = k0; k < k1; ++k) out[k] = inv * vals[k];
+    }
+}
+
 __device__ __forceinline__ int64_t row_of_entry(const int64_t* __restrict__ indptr, int64_t n_rows, int64_t k) {
     // largest r with indptr[r] <= k
     int64_t lo = 0, hi = n_rows;  // invariant: indptr[lo] <= k < indptr[hi]
@@ -410,6 +424,23 @@ int gcn_row_sums(int64_t n_rows, const int64_t* indptr, const double* vals, doub
     if (n_rows < 0 || !indptr || !rowsum_out) return fail(GCN_ERR_BAD_ARG, "bad argument");
     if (n_rows == 0) return GCN_OK;
     row_sums_kernel<<<grid_for(n_rows), kBlock, 0, (hipStream_t)stream>>>(n_rows, indptr, vals, rowsum_out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_row_normalize(int64_t n_rows, int64_t nnz, const int64_t* indptr, const void* vals, int val_bytes,
+                      void* vals_out, void* stream) {
+    if (n_rows < 0 || nnz < 0 || !indptr || (nnz > 0 && (!vals || !vals_out)))
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (val_bytes != 4 && val_bytes != 8) return fail(GCN_ERR_BAD_ARG, "val_bytes must be 4 or 8");
+    if (n_rows == 0 || nnz == 0) return GCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (val_bytes == 4)
+        row_normalize_kernel<float><<<grid_for(n_rows), kBlock, 0, st>>>(n_rows, indptr, (const float*)vals,
+                                                                         (float*)vals_out);
+    else
+        row_normalize_kernel<double><<<grid_for(n_rows), kBlock, 0, st>>>(n_rows, indptr, (const double*)vals,
+                                                                          (double*)vals_out);
     GCN_LAUNCH_CHECK();
     return GCN_OK;
 }

@@ -194,12 +194,19 @@ __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const i
     }
 }
 
+// out = act(acc + addend): the addend row (may be null) is the "+ X" of a smoothing step
 template <int VEC, int VPL>
-__device__ __forceinline__ void store_row(float* dst, const int (&col)[VPL], const bool (&on)[VPL],
-                                          float (&acc)[VPL][VEC], bool relu) {
+__device__ __forceinline__ void store_row(float* dst, const float* addend, const int (&col)[VPL],
+                                          const bool (&on)[VPL], float (&acc)[VPL][VEC], bool relu) {
 #pragma unroll
     for (int v = 0; v < VPL; ++v)
         if (on[v]) {
+            if (addend) {
+                float d[VEC];
+                load_vec<VEC>(addend + col[v], d);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[v][e] = __fadd_rn(acc[v][e], d[e]);
+            }
             if (relu) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[v][e] = acc[v][e] > 0.0f ? acc[v][e] : 0.0f;
@@ -214,7 +221,8 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                              uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
-                                             const DropArgs& dr, int split) {
+                                             const DropArgs& dr, int split, const float* __restrict__ add,
+                                             int64_t ldadd) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;  // columns covered per pass
     const int lane = threadIdx.x & 63;
@@ -244,7 +252,8 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
             accumulate_range<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
-            store_row<VEC, VPL>(c + (int64_t)r * ldc, col, on, acc, relu != 0);
+            store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
+                                relu != 0);
         }
     }
 }
@@ -256,7 +265,8 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                                             const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                             const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                             uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
-                                            const DropArgs& dr, int split) {
+                                            const DropArgs& dr, int split, const float* __restrict__ add,
+                                            int64_t ldadd) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
@@ -295,7 +305,9 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
             const bool idle = live && (k >= k1);
             const uint64_t m = __ballot(idle) & leaders;
             if (idle) {
-                if (r >= 0) store_row<VEC, VPL>(c + (int64_t)r * ldc, col, on, acc, relu != 0);
+                if (r >= 0)
+                    store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
+                                        relu != 0);
                 const int rn = r_next + __popcll(m & below);
                 r = -1;
                 k = 0;
@@ -397,7 +409,7 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
         accumulate_range<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
-        store_row<VEC, VPL>(part + chunk * ldp, col, on, acc, false);
+        store_row<VEC, VPL>(part + chunk * ldp, nullptr, col, on, acc, false);
     }
 }
 
@@ -419,17 +431,18 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
                                                            const float* __restrict__ b, uint32_t ldb,
                                                            float* __restrict__ c, int64_t ldc,
                                                            float* __restrict__ part, int64_t ldp, int relu,
-                                                           DropArgs dr) {
+                                                           DropArgs dr, const float* __restrict__ add,
+                                                           int64_t ldadd) {
     const int64_t block = blockIdx.x;
     if (block < pv.chunk_blocks)
         chunks_block<LPR, VEC, VPL, DROPOUT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
                                              indices, vals, f, b, ldb, part, ldp, dr, pv.split);
     else if (LPR >= 32)
         strips_block<LPR, VEC, VPL, DROPOUT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
-                                             vals, f, b, ldb, c, ldc, relu, dr, pv.split);
+                                             vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd);
     else
         slots_block<LPR, VEC, VPL, DROPOUT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
-                                            vals, f, b, ldb, c, ldc, relu, dr, pv.split);
+                                            vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd);
 }
 
 // partial rows of each long row, added in chunk order; one wave per long row.  Partial rows are
@@ -439,13 +452,15 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(int64_t n_long
                                                                   const int64_t* __restrict__ long_chunk, int64_t f,
                                                                   const float* __restrict__ part, int64_t ldp,
                                                                   float* __restrict__ c, int64_t ldc, int relu,
-                                                                  int vec_c) {
+                                                                  int vec_c, const float* __restrict__ add,
+                                                                  int64_t ldadd) {
     constexpr int kDepth = 8;
     const int lane = threadIdx.x & 63;
     const int64_t li = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (li >= n_long) return;
     const int64_t c0 = long_chunk[li], c1 = long_chunk[li + 1];
     float* dst = c + (int64_t)long_row[li] * ldc;
+    const float* addrow = add ? add + (int64_t)long_row[li] * ldadd : nullptr;
     for (int64_t j = (int64_t)lane * 4; j < f; j += 256) {
         float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         const float* src = part + j;
@@ -464,6 +479,11 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(int64_t n_long
             load_vec<4>(src + ch * ldp, x);
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], x[e]);
+        }
+        if (addrow) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j + e < f) s[e] = __fadd_rn(s[e], addrow[j + e]);
         }
         if (relu) {
 #pragma unroll
@@ -496,6 +516,8 @@ struct SpmmCall {
     float* part;
     int64_t ldp;
     DropArgs dr;
+    const float* add;
+    int64_t ldadd;
     hipStream_t st;
 };
 
@@ -520,13 +542,14 @@ static int launch_variant(const SpmmCall& a) {
     if (grid > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[0], a.st));
     spmm_rows_kernel<LPR, VEC, VPL, DROPOUT><<<(unsigned)grid, kBlock, 0, a.st>>>(
-        pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr);
+        pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add, a.ldadd);
     GCN_LAUNCH_CHECK();
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[1], a.st));
     if (lt.n_chunks > 0) {
         const unsigned grid2 = (unsigned)ceil_div(lt.n_long, kWaves);
         spmm_long_reduce_kernel<<<grid2, kBlock, 0, a.st>>>(lt.n_long, lt.long_row, lt.long_chunk, a.f, a.part,
-                                                            a.ldp, a.c, a.ldc, a.relu, VEC == 4 ? 1 : 0);
+                                                            a.ldp, a.c, a.ldc, a.relu, VEC == 4 ? 1 : 0, a.add,
+                                                            a.ldadd);
         GCN_LAUNCH_CHECK();
     }
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[2], a.st));
@@ -553,8 +576,10 @@ static inline int64_t partial_ld(int64_t f) { return (f + 3) / 4 * 4; }
 template <bool DROPOUT>
 static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
                       int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
-                      size_t workspace_bytes, DropArgs dr, void* stream) {
+                      size_t workspace_bytes, DropArgs dr, void* stream, const float* add = nullptr,
+                      int64_t ldadd = 0) {
     if (!plan) return fail(GCN_ERR_BAD_ARG, "plan is null");
+    if (add && ldadd < f) return fail(GCN_ERR_BAD_ARG, "bad addend leading dimension %lld", (long long)ldadd);
     if (f < 0 || ldb < f || ldc < f || ldb > INT32_MAX || f > INT32_MAX - 1024)
         return fail(GCN_ERR_BAD_ARG, "bad width: f=%lld ldb=%lld ldc=%lld", (long long)f, (long long)ldb, (long long)ldc);
     if (!indptr || (plan->nnz > 0 && (!indices || !vals))) return fail(GCN_ERR_BAD_ARG, "null CSR pointer");
@@ -575,6 +600,8 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
     a.part = nullptr;
     a.ldp = partial_ld(f);
     a.dr = dr;
+    a.add = add;
+    a.ldadd = ldadd;
     a.st = (hipStream_t)stream;
     const int64_t max_chunks = std::max(plan->table[0].n_chunks, plan->table[1].n_chunks);
     if (max_chunks > 0) {
@@ -584,7 +611,8 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
         if (!aligned16(workspace)) return fail(GCN_ERR_BAD_ARG, "workspace must be 16-byte aligned");
         a.part = (float*)workspace;
     }
-    const bool vec4 = (f % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(b) && aligned16(c);
+    const bool vec4 = (f % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(b) && aligned16(c) &&
+                      (!add || ((ldadd % 4 == 0) && aligned16(add)));
     return vec4 ? launch_by_width<4, DROPOUT>(a) : launch_by_width<1, DROPOUT>(a);
 }
 
@@ -765,6 +793,15 @@ int gcn_spmm_csr_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int
     DropArgs dr = {nullptr, 0, 1.0f, 1.0f};
     return spmm_entry<false>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
                              stream);
+}
+
+int gcn_spmm_csr_add_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
+                         int64_t f, const float* b, int64_t ldb, const float* add, int64_t ldadd, float* c,
+                         int64_t ldc, int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!add) return fail(GCN_ERR_BAD_ARG, "addend is null");
+    DropArgs dr = {nullptr, 0, 1.0f, 1.0f};
+    return spmm_entry<false>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
+                             stream, add, ldadd);
 }
 
 int gcn_spmm_csr_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,

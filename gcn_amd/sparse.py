@@ -304,6 +304,33 @@ def spmm(a, b, relu=False, out=None):
     return out
 
 
+def spmm_add(a, b, d, relu=False, out=None):
+    """``a @ b + d`` with the addition fused into the product's epilogue (one smoothing step)."""
+    _require_cuda(b, d)
+    b, d = _rowmajor(b), _rowmajor(d)
+    if b.shape[0] != a.n_cols or d.shape != (a.n_rows, b.shape[1]):
+        raise ValueError('shape mismatch in spmm_add')
+    f = b.shape[1]
+    if out is None:
+        out = torch.empty((a.n_rows, f), dtype=torch.float32, device=b.device)
+    ws, ws_bytes = a.plan.workspace(f, b.device)
+    _lib.call('gcn_spmm_csr_add_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(b), _ld(b),
+              _p(d), _ld(d), _p(out), _ld(out), _lib.GCN_RELU if relu else 0, _p(ws), ws_bytes, _stream())
+    return out
+
+
+def row_normalize(indptr, vals):
+    """Bag-of-words scaling r_inv[row] * value (gcn/utils.py:279-285) of CSR values (float32 or float64)."""
+    _require_cuda(indptr, vals)
+    if vals.dtype not in (torch.float32, torch.float64):
+        raise ValueError('values must be float32 or float64')
+    vals = vals.contiguous()
+    out = torch.empty_like(vals)
+    _lib.call('gcn_row_normalize', indptr.numel() - 1, vals.numel(), _p(indptr), _p(vals), vals.element_size(),
+              _p(out), _stream())
+    return out
+
+
 def spmm_dropout(a, b, keep_prob, seed, stream_id, relu=False, out=None):
     """``sparse_dropout(a, keep_prob) @ b`` with the dropout fused into the product.
     Entry ids for the random stream come from ``a.perm`` when ``a`` is a transposed copy."""

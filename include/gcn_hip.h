@@ -153,6 +153,13 @@ int gcn_spmm_csr_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int
                      int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* C = A . B + D: one smoothing / propagation step with the residual added in the epilogue
+ * (`new_feature = adj * new_feature + features`, gcn/utils.py:568-569; float32 here).  D is a
+ * dense [n_rows x f] matrix; GCN_RELU applies after the addition. */
+int gcn_spmm_csr_add_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
+                         int64_t f, const float* b, int64_t ldb, const float* add, int64_t ldadd, float* c,
+                         int64_t ldc, int flags, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Same product with sparse_dropout (gcn/layers.py:19-25) fused on A's entries:
  * entry k is kept iff floor(keep_prob + u_k) == 1 in float32 and then scaled by
  * float32(1/keep_prob); u_k is the counter-based uniform of entry id
@@ -166,6 +173,13 @@ int gcn_spmm_csr_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, c
 /* ------------------------------------------------------------------------- *
  * Dense pieces of the layer.                                                 *
  * ------------------------------------------------------------------------- */
+
+/* rowsum^-1 scaling of a CSR matrix in place of `r_mat_inv.dot(features)` -- the bag-of-words
+ * normalisation of gcn/utils.py:279-285: vals_out[k] = r_inv[row(k)] * vals[k], r_inv = 1 / rowsum with
+ * inf -> 0, in the value type of the matrix (val_bytes 4 or 8; the row sum itself is taken in
+ * float64 as `features.sum(1)` over a float64 LIL matrix does). */
+int gcn_row_normalize(int64_t n_rows, int64_t nnz, const int64_t* indptr, const void* vals, int val_bytes,
+                      void* vals_out, void* stream);
 
 /* y = (x / keep_prob) * floor(keep_prob + u): tf.nn.dropout at gcn/layers.py:185.
  * gate (may be NULL): additionally y = 0 where gate <= 0 (ReLU backward). */
