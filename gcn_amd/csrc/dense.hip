@@ -11,14 +11,14 @@ constexpr int kBlock = 256;
 // ------------------------------------------------------------------------------------------------
 __global__ void dropout_kernel(int64_t n_rows, int64_t f, const float* __restrict__ x, int64_t ldx,
                                const float* __restrict__ gate, int64_t ldg, float* __restrict__ y, int64_t ldy,
-                               float keep_prob, uint64_t key) {
+                               float keep_prob, uint64_t key, uint64_t index_offset) {
     const int64_t total = n_rows * f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / f, c = i - r * f;
         float v = x[r * ldx + c];
         // TF 1.x: div(x, keep_prob) * floor(keep_prob + uniform)
         v = __fdiv_rn(v, keep_prob);
-        v = keep_entry(key, (uint64_t)i, keep_prob) ? v : 0.0f;
+        v = keep_entry(key, index_offset + (uint64_t)i, keep_prob) ? v : 0.0f;
         if (gate && !(gate[r * ldg + c] > 0.0f)) v = 0.0f;
         y[r * ldy + c] = v;
     }
@@ -215,7 +215,8 @@ using namespace gcn;
 extern "C" {
 
 int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, const float* gate, int64_t ldg, float* y,
-                    int64_t ldy, float keep_prob, uint64_t seed, uint64_t stream_id, void* stream) {
+                    int64_t ldy, float keep_prob, uint64_t seed, uint64_t stream_id, uint64_t index_offset,
+                    void* stream) {
     if (n_rows < 0 || f < 0 || ldx < f || ldy < f || (gate && ldg < f)) return fail(GCN_ERR_BAD_ARG, "bad shape");
     if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
     const int64_t total = n_rows * f;
@@ -224,7 +225,7 @@ int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, cons
     int64_t blocks = ceil_div(total, kBlock);
     if (blocks > 256 * 32) blocks = 256 * 32;
     dropout_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_rows, f, x, ldx, gate, ldg, y, ldy,
-                                                                        keep_prob, stream_key(seed, stream_id));
+                                                                        keep_prob, stream_key(seed, stream_id), index_offset);
     GCN_LAUNCH_CHECK();
     return GCN_OK;
 }

@@ -12,6 +12,43 @@ import torch.distributed as dist
 from . import sparse
 
 
+def _through_host(t, group):
+    """gloo moves host memory; device tensors are staged explicitly so that the rehearsal of the
+    multi-rank path on one GPU never depends on gloo's own device-copy streams.  RCCL ('nccl')
+    works on device memory directly."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def all_to_all_rows(out, inp, out_splits=None, in_splits=None, group=None):
+    if _through_host(out, group):
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host_out, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(host_out)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+    return out
+
+
+def all_reduce_sum(t, group=None):
+    if _through_host(t, group):
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def all_gather_rows(out, inp, group=None):
+    if _through_host(out, group):
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host_out, inp.cpu(), group=group)
+        out.copy_(host_out)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+    return out
+
+
 def row_block(n_rows, rank, world):
     """Contiguous equal split; n_rows must be padded by the caller to a multiple of world."""
     if n_rows % world != 0:
@@ -51,30 +88,29 @@ class AllGatherSpmm(object):
 
     def __call__(self, b_local, relu=False):
         if self.shard.world > 1:
-            dist.all_gather_into_tensor(self.b_full, b_local.contiguous(), group=self.group)
+            all_gather_rows(self.b_full, b_local.contiguous(), group=self.group)
         else:
             self.b_full.copy_(b_local)
         return self._spmm(self.shard.local, self.b_full, relu=relu, out=self.c_local)
 
 
-class HaloSpmm(object):
-    """C_local = A_local . B where every rank receives only the rows of B its shard references.
+class HaloPlan(object):
+    """Which rows of a row-sharded dense matrix every rank needs from every other rank.
 
     Set-up (integer work, once per graph): the distinct columns of the local shard are sorted --
     which groups them by owner rank, since owners hold contiguous blocks -- the shard's column
     indices are renumbered to positions in that list (the order of the entries inside a row does
-    not change, so sums are bit-identical), and the ranks exchange their request lists.  Per
-    product: gather the requested local rows, one ``all_to_all_single``, local product.  On a
-    skewed graph most vertices have few neighbours, so a shard references a fraction of the
-    columns (about a quarter at 8 ranks on the scale-24 R-MAT) and the exchange moves that
-    fraction of what an all-gather moves."""
+    not change, so sums are bit-identical), and the ranks exchange their request lists.
+    ``exchange(b_local)`` then gathers the requested local rows and moves them with one
+    ``all_to_all_single``.  On a skewed graph most vertices have few neighbours, so a shard
+    references a fraction of the columns (about a quarter at 8 ranks on the scale-24 R-MAT) and
+    the exchange moves that fraction of what an all-gather moves."""
 
-    def __init__(self, shard, f, group=None, spmm=None, csr_factory=None):
-        self.shard, self.f, self.group = shard, f, group
-        self._spmm = spmm or sparse.spmm
+    def __init__(self, shard, group=None, csr_factory=None):
+        self.shard, self.group = shard, group
         local = shard.local
         dev = local.device
-        world, rank = shard.world, shard.rank
+        world = shard.world
         per = shard.n_cols // world
         if shard.n_cols % world != 0:
             raise ValueError('n_cols=%d is not a multiple of the world size %d' % (shard.n_cols, world))
@@ -87,27 +123,50 @@ class HaloSpmm(object):
         # tell every owner which of its rows this rank wants
         self.send_counts = torch.empty(world, dtype=torch.int64, device=dev)
         if world > 1:
-            dist.all_to_all_single(self.send_counts, self.recv_counts, group=group)
+            all_to_all_rows(self.send_counts, self.recv_counts, group=group)
         else:
             self.send_counts.copy_(self.recv_counts)
         self.recv_splits = [int(v) for v in self.recv_counts.tolist()]
         self.send_splits = [int(v) for v in self.send_counts.tolist()]
         self.send_rows = torch.empty(sum(self.send_splits), dtype=torch.int64, device=dev)
         if world > 1:
-            dist.all_to_all_single(self.send_rows, request, self.send_splits, self.recv_splits, group=group)
+            all_to_all_rows(self.send_rows, request, self.send_splits, self.recv_splits, group=group)
         else:
             self.send_rows.copy_(request)
         make = csr_factory or sparse.DeviceCSR
         self.compact = make(local.n_rows, int(needed.numel()), local.indptr, new_cols, local.values)
         self.n_needed = int(needed.numel())
-        self.send_buf = torch.empty((self.send_rows.numel(), f), dtype=torch.float32, device=dev)
-        self.b_halo = torch.empty((self.n_needed, f), dtype=torch.float32, device=dev)
-        self.c_local = torch.empty((local.n_rows, f), dtype=torch.float32, device=dev)
+        self._buffers = {}
+
+    def exchange(self, b_local):
+        """Rows of the global matrix this rank's shard references, [n_needed x f], in column order."""
+        f = b_local.shape[1]
+        bufs = self._buffers.get(f)
+        if bufs is None:
+            dev = b_local.device
+            bufs = (torch.empty((self.send_rows.numel(), f), dtype=torch.float32, device=dev),
+                    torch.empty((self.n_needed, f), dtype=torch.float32, device=dev))
+            self._buffers[f] = bufs
+        send_buf, b_halo = bufs
+        torch.index_select(b_local, 0, self.send_rows, out=send_buf)
+        if self.shard.world > 1:
+            all_to_all_rows(b_halo, send_buf, self.recv_splits, self.send_splits, group=self.group)
+        else:
+            b_halo.copy_(send_buf)
+        return b_halo
+
+
+class HaloSpmm(object):
+    """C_local = A_local . B where every rank receives only the rows of B its shard references."""
+
+    def __init__(self, shard, f, group=None, spmm=None, csr_factory=None, plan=None):
+        self.shard, self.f = shard, f
+        self._spmm = spmm or sparse.spmm
+        self.plan = plan or HaloPlan(shard, group=group, csr_factory=csr_factory)
+        self.compact = self.plan.compact
+        self.n_needed = self.plan.n_needed
+        self.recv_splits = self.plan.recv_splits
+        self.c_local = torch.empty((shard.local.n_rows, f), dtype=torch.float32, device=shard.local.device)
 
     def __call__(self, b_local, relu=False):
-        torch.index_select(b_local, 0, self.send_rows, out=self.send_buf)
-        if self.shard.world > 1:
-            dist.all_to_all_single(self.b_halo, self.send_buf, self.recv_splits, self.send_splits, group=self.group)
-        else:
-            self.b_halo.copy_(self.send_buf)
-        return self._spmm(self.compact, self.b_halo, relu=relu, out=self.c_local)
+        return self._spmm(self.compact, self.plan.exchange(b_local), relu=relu, out=self.c_local)

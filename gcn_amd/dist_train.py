@@ -1,0 +1,112 @@
+"""A GCN training step on a row-sharded graph (one process per GPU).
+
+Forward per layer, on rank p:  P_p = H_p . W (local GEMM, W replicated)  ->  exchange of the rows of
+P this rank's shard references  ->  Z_p = A_p . P (local product).  For a symmetric support the
+backward product dP = A^T . dZ has the same shape: dP_p = A_p . exchange(dZ), so no scatter-add and
+no change in any row's accumulation order.  Weight gradients are partial sums over the local rows
+and are all-reduced; the masked loss is normalised by the global mask count.  This is the
+multi-GPU form of the step the reference times at train.py:203-205 (forward + backward + Adam).
+"""
+import numpy as np
+import torch
+
+from . import graph, sparse
+from .dist import HaloPlan, all_reduce_sum
+from .layers import _GemmFn
+from .models import TfAdam
+
+
+class _HaloSpmmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, b_local, fuse_relu):
+        out = sparse.spmm(plan.compact, plan.exchange(b_local), relu=fuse_relu)
+        ctx.plan, ctx.fuse_relu = plan, fuse_relu
+        if fuse_relu:
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        if ctx.fuse_relu:
+            out, = ctx.saved_tensors
+            grad = sparse.dropout(grad, 1.0, 0, 0, gate=out)
+        plan = ctx.plan
+        # symmetric support: rows of A^T are rows of A
+        return None, sparse.spmm(plan.compact, plan.exchange(grad.contiguous())), None
+
+
+class _ShardDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, keep_prob, seed, stream_id, index_offset):
+        ctx.args = (keep_prob, seed, stream_id, index_offset)
+        return sparse.dropout(x, keep_prob, seed, stream_id, index_offset=index_offset)
+
+    @staticmethod
+    def backward(ctx, grad):
+        keep_prob, seed, stream_id, index_offset = ctx.args
+        return sparse.dropout(grad, keep_prob, seed, stream_id, index_offset=index_offset), None, None, None, None
+
+
+class ShardedGCN(object):
+    """Dense-feature GCN (connection 'c' * L) over a ``RowShardedCSR`` with a symmetric support."""
+
+    def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
+                 seed=0, group=None):
+        self.shard, self.group = shard, group
+        self.plan = HaloPlan(shard, group=group)
+        self.dropout, self.wd, self.seed = float(dropout), float(weight_decay), int(seed)
+        sizes = [f_in] + list(layer_size) + [n_classes]
+        dev = shard.local.device
+        g = torch.Generator(device=dev)
+        g.manual_seed(self.seed)                       # every rank draws the same replicated weights
+        self.weights = []
+        for fan_in, fan_out in zip(sizes[:-1], sizes[1:]):
+            r = float(np.sqrt(6.0 / (fan_in + fan_out)))
+            w = (torch.rand((fan_in, fan_out), generator=g, device=dev, dtype=torch.float32) * 2 - 1) * r
+            self.weights.append(w.requires_grad_(True))
+        self.optimizer = TfAdam(self.weights, learning_rate)
+        self.step_count = 0
+
+    def _all_reduce(self, t):
+        if self.shard.world > 1:
+            all_reduce_sum(t, group=self.group)
+        return t
+
+    def forward(self, x_local, train):
+        keep = 1.0 - self.dropout if train else 1.0
+        h = x_local
+        last = len(self.weights) - 1
+        for li, w in enumerate(self.weights):
+            if keep < 1.0:
+                offset = self.shard.row_begin * h.shape[1]
+                h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64 + li, offset)
+            p = _GemmFn.apply(h, w)
+            h = _HaloSpmmFn.apply(self.plan, p, li != last)
+        return h
+
+    def loss_terms(self, logits, labels_local, mask_local):
+        """Local part of gcn/metrics.py:85-92 with the mask normalised globally, and the global mask mean."""
+        n_global = self.shard.n_rows_global
+        mask = mask_local.to(torch.float32)
+        mask_sum = self._all_reduce(mask.sum().detach().clone())
+        mask_mean = mask_sum / n_global
+        ce = -(labels_local.to(torch.float32) * torch.log_softmax(logits, dim=1)).sum(dim=1)
+        return (ce * mask).sum() / (mask_mean * n_global)
+
+    def train_step(self, x_local, labels_local, mask_local):
+        """One optimiser step; returns the global loss (data term + weight decay) as a 0-d tensor."""
+        self.step_count += 1
+        with torch.enable_grad():
+            logits = self.forward(x_local, train=True)
+            local = self.loss_terms(logits, labels_local, mask_local)
+            grads = torch.autograd.grad(local, self.weights)
+        flat = torch.cat([g.reshape(-1) for g in grads] + [local.detach().reshape(1)])
+        self._all_reduce(flat)
+        pos, summed = 0, []
+        for w in self.weights:
+            summed.append(flat[pos:pos + w.numel()].view_as(w) + self.wd * w.detach())   # + d/dw of wd * |w|^2 / 2
+            pos += w.numel()
+        self.optimizer.step(summed)
+        with torch.no_grad():
+            reg = sum(self.wd * (w * w).sum() / 2 for w in self.weights)
+        return flat[pos] + reg

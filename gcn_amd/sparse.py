@@ -348,15 +348,16 @@ def spmm_dropout(a, b, keep_prob, seed, stream_id, relu=False, out=None):
     return out
 
 
-def dropout(x, keep_prob, seed, stream_id, gate=None):
-    """tf.nn.dropout(x, keep_prob); with ``gate`` the result is also zeroed where gate <= 0."""
+def dropout(x, keep_prob, seed, stream_id, gate=None, index_offset=0):
+    """tf.nn.dropout(x, keep_prob); with ``gate`` the result is also zeroed where gate <= 0.
+    ``index_offset`` shifts the element ids of the random stream (row_begin * width for a row shard)."""
     _require_cuda(x, gate)
     x = _rowmajor(x)
     if gate is not None:
         gate = _rowmajor(gate)
     y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
     _lib.call('gcn_dropout_f32', x.shape[0], x.shape[1], _p(x), _ld(x), _p(gate), 0 if gate is None else _ld(gate),
-              _p(y), _ld(y), float(keep_prob), int(seed), int(stream_id), _stream())
+              _p(y), _ld(y), float(keep_prob), int(seed), int(stream_id), int(index_offset), _stream())
     return y
 
 

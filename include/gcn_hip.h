@@ -182,9 +182,12 @@ int gcn_row_normalize(int64_t n_rows, int64_t nnz, const int64_t* indptr, const 
                       void* vals_out, void* stream);
 
 /* y = (x / keep_prob) * floor(keep_prob + u): tf.nn.dropout at gcn/layers.py:185.
- * gate (may be NULL): additionally y = 0 where gate <= 0 (ReLU backward). */
+ * gate (may be NULL): additionally y = 0 where gate <= 0 (ReLU backward).
+ * Element (r, c) draws the uniform of id index_offset + r * f + c: a rank that holds the rows
+ * [r0, r1) of a larger matrix passes r0 * f and gets the mask of the unsplit matrix. */
 int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, const float* gate, int64_t ldg, float* y,
-                    int64_t ldy, float keep_prob, uint64_t seed, uint64_t stream_id, void* stream);
+                    int64_t ldy, float keep_prob, uint64_t seed, uint64_t stream_id, uint64_t index_offset,
+                    void* stream);
 
 /* C[m x n] = A . op(B) in float32 on the f32 MFMA pipe: tf.matmul at
  * gcn/layers.py:32-33 (H . W).  A is [m x k]; trans_b = 0: B is [k x n];

@@ -1,6 +1,7 @@
 """GPU, 2 ranks sharing cuda:0 over gloo: the row-sharded product with the HIP kernels.  Both
 exchange forms (all-gather of B, exchange of the referenced rows only) must reproduce the
 single-GPU product bit for bit, because no row's accumulation order changes."""
+import faulthandler
 import os
 import sys
 
@@ -16,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _worker(rank, world, port, result_dir, scale, f):
+    faulthandler.dump_traceback_later(90, exit=True)      # a stuck collective names itself and ends the rank
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -57,3 +59,52 @@ def test_two_rank_product_equals_single_gpu(f, tmp_path):
     # rows up to the split threshold are summed serially on both sides: identical bits; a longer row is
     # cut at the same places too, because a shard keeps whole rows
     assert np.array_equal(got, ref)
+
+
+def _train_worker(rank, world, port, result_dir, scale, steps):
+    if world > 1:
+        faulthandler.dump_traceback_later(90, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from gcn_amd import dist as gdist, sparse
+        from gcn_amd.dist_train import ShardedGCN
+        n, f_in, classes = 1 << scale, 32, 8
+        indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+        d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+        vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+        shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, rank, world)
+        r0, r1 = shard.row_begin, shard.row_end
+        x = sparse.synthetic_dense(n, f_in, seed=7)[r0:r1].contiguous()
+        gen = torch.Generator().manual_seed(5)
+        cls = torch.randint(0, classes, (n,), generator=gen)
+        labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32)[r0:r1].cuda()
+        mask = (torch.rand(n, generator=gen) < 0.05).to(torch.int32)[r0:r1].cuda()
+        model = ShardedGCN(shard, f_in, [16], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9)
+        losses = [float(model.train_step(x, labels, mask)) for _ in range(steps)]
+        if rank == 0:
+            np.save(os.path.join(result_dir, 'loss_w%d.npy' % world), np.array(losses))
+            np.save(os.path.join(result_dir, 'w0_w%d.npy' % world), model.weights[0].detach().cpu().numpy())
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_sharded_training_step_matches_single_gpu(tmp_path):
+    """Forward + backward + Adam on 2 ranks (exchange of referenced rows in both directions, all-reduced
+    weight gradients, the unsplit dropout masks) against the same model on 1 rank."""
+    scale, steps = 13, 4
+    port = 29800 + (os.getpid() % 1000)
+    _train_worker(0, 1, port, str(tmp_path), scale, steps)
+    mp.start_processes(_train_worker, args=(2, port + 1, str(tmp_path), scale, steps), nprocs=2, join=True,
+                       start_method='spawn')
+    l1, l2 = np.load(tmp_path / 'loss_w1.npy'), np.load(tmp_path / 'loss_w2.npy')
+    assert np.all(np.isfinite(l1)) and l1[-1] < l1[0]
+    assert np.allclose(l1, l2, rtol=1e-5)
+    w1, w2 = np.load(tmp_path / 'w0_w1.npy'), np.load(tmp_path / 'w0_w2.npy')
+    d = np.abs(w1 - w2)
+    assert (d <= 1e-5 * np.abs(w1).max()).mean() >= 0.999 and d.max() <= 1e-3 * np.abs(w1).max()
