@@ -18,6 +18,7 @@ GCN_ERR_WORKSPACE = 4
 GCN_ADD_SELF_LOOPS = 1
 GCN_BINARY = 2
 GCN_RELU = 1
+GCN_SPLIT_WIDE = 4
 GCN_NORM_SYM = 0
 GCN_NORM_RW = 1
 

@@ -513,6 +513,7 @@ struct SpmmCall {
     float* c;
     int64_t ldc;
     int relu;
+    int wide_split;
     float* part;
     int64_t ldp;
     DropArgs dr;
@@ -526,7 +527,7 @@ static int launch_variant(const SpmmCall& a) {
     const gcn_spmm_plan* p = a.plan;
     constexpr int kWaves = kBlock / 64;
     constexpr int kGroups = 64 / LPR;
-    const int ti = (LPR >= 32) ? 1 : 0;
+    const int ti = (LPR >= 32 || a.wide_split) ? 1 : 0;
     const gcn_spmm_plan::LongTable& lt = p->table[ti];
     PlanView pv;
     pv.n_strips = p->n_strips;
@@ -585,7 +586,7 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
     if (!indptr || (plan->nnz > 0 && (!indices || !vals))) return fail(GCN_ERR_BAD_ARG, "null CSR pointer");
     if (plan->n_rows == 0 || f == 0) return GCN_OK;
     if (!c || (plan->nnz > 0 && !b)) return fail(GCN_ERR_BAD_ARG, "null dense pointer");
-    if (flags & ~GCN_RELU) return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    if (flags & ~(GCN_RELU | GCN_SPLIT_WIDE)) return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
     SpmmCall a;
     a.plan = plan;
     a.indptr = indptr;
@@ -597,6 +598,7 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
     a.c = c;
     a.ldc = ldc;
     a.relu = (flags & GCN_RELU) ? 1 : 0;
+    a.wide_split = (flags & GCN_SPLIT_WIDE) ? 1 : 0;
     a.part = nullptr;
     a.ldp = partial_ld(f);
     a.dr = dr;

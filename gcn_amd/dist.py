@@ -122,14 +122,16 @@ class HaloPlan(object):
         request = (needed - owner * per).contiguous()                # row offsets inside the owner's block
         # tell every owner which of its rows this rank wants
         self.send_counts = torch.empty(world, dtype=torch.int64, device=dev)
-        if world > 1:
+        # a 1-rank process group still goes through the collectives (same code path as N ranks)
+        self._collective = world > 1 or (dist.is_initialized() and dist.get_world_size(group) == 1)
+        if self._collective:
             all_to_all_rows(self.send_counts, self.recv_counts, group=group)
         else:
             self.send_counts.copy_(self.recv_counts)
         self.recv_splits = [int(v) for v in self.recv_counts.tolist()]
         self.send_splits = [int(v) for v in self.send_counts.tolist()]
         self.send_rows = torch.empty(sum(self.send_splits), dtype=torch.int64, device=dev)
-        if world > 1:
+        if self._collective:
             all_to_all_rows(self.send_rows, request, self.send_splits, self.recv_splits, group=group)
         else:
             self.send_rows.copy_(request)
@@ -138,35 +140,86 @@ class HaloPlan(object):
         self.n_needed = int(needed.numel())
         self._buffers = {}
 
-    def exchange(self, b_local):
-        """Rows of the global matrix this rank's shard references, [n_needed x f], in column order."""
+    def exchange(self, b_local, slot=0, async_op=False):
+        """Rows of the global matrix this rank's shard references, [n_needed x f], in column order.
+
+        ``slot`` picks one of the cached buffer pairs of this width, so that a caller can have one
+        exchange in flight while the product reads the previous one.  With ``async_op`` the pair
+        ``(rows, work)`` is returned and ``work.wait()`` orders the current stream after the
+        exchange; RCCL runs it on its own stream, which is what lets it overlap a product enqueued
+        after the call."""
         f = b_local.shape[1]
-        bufs = self._buffers.get(f)
+        bufs = self._buffers.get((f, slot))
         if bufs is None:
             dev = b_local.device
             bufs = (torch.empty((self.send_rows.numel(), f), dtype=torch.float32, device=dev),
                     torch.empty((self.n_needed, f), dtype=torch.float32, device=dev))
-            self._buffers[f] = bufs
+            self._buffers[(f, slot)] = bufs
         send_buf, b_halo = bufs
         torch.index_select(b_local, 0, self.send_rows, out=send_buf)
-        if self.shard.world > 1:
-            all_to_all_rows(b_halo, send_buf, self.recv_splits, self.send_splits, group=self.group)
+        work = _Done
+        if self._collective:
+            if async_op and not _through_host(b_halo, self.group):
+                work = dist.all_to_all_single(b_halo, send_buf, self.recv_splits, self.send_splits, group=self.group,
+                                              async_op=True)
+            else:
+                all_to_all_rows(b_halo, send_buf, self.recv_splits, self.send_splits, group=self.group)
         else:
             b_halo.copy_(send_buf)
-        return b_halo
+        return (b_halo, work) if async_op else b_halo
+
+
+class _Done(object):
+    """Stands for the handle of an exchange that has already completed."""
+    @staticmethod
+    def wait():
+        return True
+
+
+def column_chunks(f, chunks):
+    """Split f feature columns into at most ``chunks`` contiguous ranges whose widths are multiples
+    of 4 floats (128-bit loads stay possible in every range)."""
+    if chunks <= 1 or f < 8:
+        return [(0, f)]
+    quads = (f + 3) // 4
+    chunks = min(chunks, quads)
+    bounds, start = [], 0
+    for i in range(chunks):
+        stop = min(f, 4 * ((quads * (i + 1)) // chunks))
+        if stop > start:
+            bounds.append((start, stop))
+        start = stop
+    return bounds
 
 
 class HaloSpmm(object):
-    """C_local = A_local . B where every rank receives only the rows of B its shard references."""
+    """C_local = A_local . B where every rank receives only the rows of B its shard references.
 
-    def __init__(self, shard, f, group=None, spmm=None, csr_factory=None, plan=None):
+    With ``chunks`` > 1 the feature columns are cut into that many ranges and the exchange of range
+    i+1 is in flight while the product of range i runs (each output column depends on the same
+    column of B only, and every row still accumulates in storage order, so the result does not
+    change by a bit).  The first range's exchange is the only one the product waits for."""
+
+    def __init__(self, shard, f, group=None, spmm=None, csr_factory=None, plan=None, chunks=1):
         self.shard, self.f = shard, f
         self._spmm = spmm or sparse.spmm
         self.plan = plan or HaloPlan(shard, group=group, csr_factory=csr_factory)
         self.compact = self.plan.compact
         self.n_needed = self.plan.n_needed
         self.recv_splits = self.plan.recv_splits
+        self.ranges = column_chunks(f, chunks)
         self.c_local = torch.empty((shard.local.n_rows, f), dtype=torch.float32, device=shard.local.device)
 
     def __call__(self, b_local, relu=False):
-        return self._spmm(self.compact, self.plan.exchange(b_local), relu=relu, out=self.c_local)
+        if len(self.ranges) == 1:
+            return self._spmm(self.compact, self.plan.exchange(b_local), relu=relu, out=self.c_local)
+        c0, c1 = self.ranges[0]
+        pending = self.plan.exchange(b_local[:, c0:c1], slot=0, async_op=True)
+        for i, (c0, c1) in enumerate(self.ranges):
+            rows, work = pending
+            if i + 1 < len(self.ranges):
+                n0, n1 = self.ranges[i + 1]
+                pending = self.plan.exchange(b_local[:, n0:n1], slot=(i + 1) & 1, async_op=True)
+            work.wait()
+            self._spmm(self.compact, rows, relu=relu, out=self.c_local[:, c0:c1], wide_split=self.f >= 128)
+        return self.c_local

@@ -289,8 +289,18 @@ def synthetic_dense(n, f, seed=7, device='cuda'):
 # --------------------------------------------------------------------------- #
 # products
 # --------------------------------------------------------------------------- #
-def spmm(a, b, relu=False, out=None):
-    """``a @ b`` for a DeviceCSR ``a`` and dense float32 ``b`` (optionally with ReLU fused)."""
+def _check_out(out, n_rows, f):
+    """An output may be a column slice of a wider row-major matrix (its row stride is passed as ldc)."""
+    _require_cuda(out)
+    if tuple(out.shape) != (n_rows, f) or out.dtype != torch.float32 or (f > 1 and out.stride(1) != 1) \
+            or (n_rows > 1 and out.stride(0) < f):
+        raise ValueError('out must be a row-major float32 [%d x %d] view' % (n_rows, f))
+
+
+def spmm(a, b, relu=False, out=None, wide_split=False):
+    """``a @ b`` for a DeviceCSR ``a`` and dense float32 ``b`` (optionally with ReLU fused).
+    ``wide_split`` cuts long rows as a wide product does, whatever the width of ``b``: use it when
+    ``b`` is a range of the columns of a wider operand and the bits must match the full product."""
     _require_cuda(b)
     b = _rowmajor(b)
     if b.shape[0] != a.n_cols:
@@ -298,9 +308,12 @@ def spmm(a, b, relu=False, out=None):
     f = b.shape[1]
     if out is None:
         out = torch.empty((a.n_rows, f), dtype=torch.float32, device=b.device)
+    else:
+        _check_out(out, a.n_rows, f)
     ws, ws_bytes = a.plan.workspace(f, b.device)
     _lib.call('gcn_spmm_csr_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(b), _ld(b),
-              _p(out), _ld(out), _lib.GCN_RELU if relu else 0, _p(ws), ws_bytes, _stream())
+              _p(out), _ld(out), (_lib.GCN_RELU if relu else 0) | (_lib.GCN_SPLIT_WIDE if wide_split else 0), _p(ws),
+              ws_bytes, _stream())
     return out
 
 

@@ -41,6 +41,8 @@ typedef enum {
 #define GCN_BINARY 2          /* duplicates collapse to one entry of value 1 (simple graph, no values out) */
 /* flags of the SpMM / GEMM entry points */
 #define GCN_RELU 1            /* act = relu fused into the epilogue                  (gcn/layers.py:214, models.py:17) */
+#define GCN_SPLIT_WIDE 4      /* spmm: cut long rows every 1024 entries whatever the width, so that a product
+                                 computed over ranges of feature columns equals the full-width one bit for bit */
 /* type of gcn_normalize_adj */
 #define GCN_NORM_SYM 0        /* D^-1/2 A D^-1/2                                     (gcn/utils.py:299-308) */
 #define GCN_NORM_RW 1         /* D^-1 A                                              (gcn/utils.py:309-315) */

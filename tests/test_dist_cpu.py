@@ -27,7 +27,7 @@ class _HostCSR(object):
         return int(self.indices.numel())
 
 
-def _oracle_spmm(a, b, relu=False, out=None):
+def _oracle_spmm(a, b, relu=False, out=None, wide_split=False):
     import gcn_oracle
     c = gcn_oracle.spmm_csr(a.indptr.numpy(), a.indices.numpy(), a.values.numpy(), b.numpy(), relu=relu)
     out.copy_(torch.from_numpy(c))
@@ -68,6 +68,10 @@ def _worker(rank, world, port, result_dir):
         assert torch.equal(c_halo, c_local)
         assert halo.n_needed <= n_pad and sum(halo.recv_splits) == halo.n_needed
         np.save(os.path.join(result_dir, 'needed_%d.npy' % rank), np.array([halo.n_needed]))
+        # pipelined over ranges of feature columns (uneven ranges, two buffer slots): still the same bits
+        piped = gdist.HaloSpmm(shard, f, spmm=_oracle_spmm, plan=halo.plan, chunks=3)
+        assert piped.ranges == [(0, 4), (4, 8), (8, 16)]
+        assert torch.equal(piped(torch.from_numpy(b[r0:r1].copy()), relu=True), c_local)
         # the MAX-over-ranks timing reduction bench.py uses
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -89,6 +93,17 @@ def test_row_sharded_product_equals_single_process(world, oracle, tmp_path):
     assert np.array_equal(got, ref)          # same per-row order on every rank: bit-identical
     for r in range(world):                   # a shard references only part of the columns
         assert int(np.load(os.path.join(str(tmp_path), 'needed_%d.npy' % r))[0]) < n
+
+
+def test_column_chunks_cover_every_column_once():
+    sys.path.insert(0, ROOT)
+    from gcn_amd import dist as gdist
+    for f in (1, 6, 7, 16, 100, 256, 513):
+        for chunks in (1, 2, 4, 7):
+            ranges = gdist.column_chunks(f, chunks)
+            assert ranges[0][0] == 0 and ranges[-1][1] == f and len(ranges) <= max(chunks, 1)
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            assert all(lo % 4 == 0 and hi > lo for lo, hi in ranges)
 
 
 def test_row_block_requires_equal_blocks():

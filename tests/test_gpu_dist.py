@@ -37,6 +37,8 @@ def _worker(rank, world, port, result_dir, scale, f):
         c_halo = halo(b_local, relu=True)
         assert torch.equal(c_gather, c_halo)
         assert halo.n_needed < n                 # most low-degree vertices are not referenced by a shard
+        piped = gdist.HaloSpmm(shard, f, plan=halo.plan, chunks=4)
+        assert torch.equal(piped(b_local, relu=True), c_halo)
         np.save(os.path.join(result_dir, 'c_%d.npy' % rank), c_halo.cpu().numpy())
     finally:
         dist.destroy_process_group()
@@ -59,6 +61,47 @@ def test_two_rank_product_equals_single_gpu(f, tmp_path):
     # rows up to the split threshold are summed serially on both sides: identical bits; a longer row is
     # cut at the same places too, because a shard keeps whole rows
     assert np.array_equal(got, ref)
+
+
+def _single_rank_rccl_worker(rank, port, result_dir):
+    faulthandler.dump_traceback_later(90, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        from gcn_amd import dist as gdist, sparse
+        scale, f = 13, 256
+        n = 1 << scale
+        indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+        d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+        vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+        b = sparse.synthetic_dense(n, f, seed=7)
+        ref = sparse.spmm(sparse.DeviceCSR(n, n, indptr, indices, vals), b, relu=True)
+        shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, 1)
+        piped = gdist.HaloSpmm(shard, f, chunks=4)
+        assert piped.plan._collective
+        for _ in range(3):                         # buffers are reused across calls
+            got = piped(b, relu=True)
+            assert torch.equal(got, ref)
+        gathered = gdist.AllGatherSpmm(shard, f)(b, relu=True)
+        assert torch.equal(gathered, ref)
+        t = torch.ones(4, device='cuda')
+        gdist.all_reduce_sum(t)
+        assert float(t.sum()) == 4.0
+        open(os.path.join(result_dir, 'ok'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_in_flight_over_rccl(tmp_path):
+    """The RCCL form of the exchange (asynchronous all-to-all on RCCL's stream, the product of the
+    previous column range on the caller's stream) on a 1-rank communicator: the only RCCL world one
+    GPU allows, and the same calls, stream ordering and buffer reuse as N ranks."""
+    port = 29600 + (os.getpid() % 1000)
+    mp.start_processes(_single_rank_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True, start_method='spawn')
+    assert (tmp_path / 'ok').exists()
 
 
 def _train_worker(rank, world, port, result_dir, scale, steps):
