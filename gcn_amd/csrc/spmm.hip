@@ -2,7 +2,9 @@
 // sparse dropout (gcn/layers.py:19-25, 198-199).  HBM-bound gather kernels for gfx950.
 //
 // Work decomposition
-//   strips : the nnz axis is cut every kStripNnz entries; the rows that START inside a strip belong to
+//   strips : the work axis -- entries plus kRowCost per row, so that a run of very short rows does
+//            not count as no work -- is cut every strip_nnz units (256; fewer on a matrix too small
+//            to fill the chip with such strips); the rows that START inside a strip belong to
 //            it, so strips carry equal work however skewed the degrees are.  A lane group of LPR lanes
 //            owns one row at a time; a lane holds VPL vectors of VEC floats of that row.  Wide rows
 //            (LPR = 64): one wave per strip, rows one after the other.  Narrow rows (LPR < 64): a
@@ -22,6 +24,7 @@
 struct gcn_spmm_plan {
     int64_t n_rows, n_cols, nnz;
     int64_t n_strips;
+    int strip_nnz;       // entries per strip
     int device;
     int32_t* strip_row;  // [n_strips + 1] first row starting in each strip
     // rows longer than the split threshold, cut in chunks of that many entries; table 0 serves narrow
@@ -38,7 +41,19 @@ struct gcn_spmm_plan {
 
 namespace gcn {
 
-constexpr int kStripNnz = 256;
+constexpr int kStripNnz = 256;       // entries per strip on a matrix large enough to fill the chip with such strips
+constexpr int kStripNnzMin = 16;
+constexpr int kRowCost = 4;          // a row's fixed cost (pointer loads, store) in units of one entry
+constexpr int64_t kStripsWanted = 8192;  // 8 waves on each of the 1024 SIMDs
+
+// A strip is one wave's sequential work (wide operands).  With 256-entry strips a matrix of 10^5
+// entries gives a few hundred waves, each walking 64 dependent batches of loads: the product is
+// then bound by that latency chain, not by bandwidth.  Shorter strips trade it for parallelism.
+static inline int strip_nnz_for(int64_t work) {
+    int s = kStripNnz;
+    while (s > kStripNnzMin && work / s < kStripsWanted) s >>= 1;
+    return s;
+}
 constexpr int kSplitNarrow = 256;   // lane groups narrower than a wave: every work item <= 256 entries
 constexpr int kSplitWide = 1024;    // one wave per row
 static inline int split_of(int table) { return table == 0 ? kSplitNarrow : kSplitWide; }
@@ -49,18 +64,18 @@ constexpr int kUnroll = 4;
 // plan kernels
 // ------------------------------------------------------------------------------------------------
 __global__ void strip_rows_kernel(int64_t n_rows, const int64_t* __restrict__ indptr, int64_t n_strips,
-                                  int32_t* __restrict__ strip_row) {
+                                  int strip_nnz, int32_t* __restrict__ strip_row) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w > n_strips) return;
     if (w == n_strips) {
         strip_row[w] = (int32_t)n_rows;  // trailing empty rows belong to the last strip
         return;
     }
-    const int64_t target = w * kStripNnz;
-    int64_t lo = 0, hi = n_rows;  // smallest r in [0, n_rows] with indptr[r] >= target
+    const int64_t target = w * strip_nnz;
+    int64_t lo = 0, hi = n_rows;  // smallest r in [0, n_rows] with work before row r >= target
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (indptr[mid] >= target)
+        if (indptr[mid] + mid * kRowCost >= target)
             hi = mid;
         else
             lo = mid + 1;
@@ -638,7 +653,9 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
     p->n_rows = n_rows;
     p->n_cols = n_cols;
     p->nnz = nnz;
-    p->n_strips = std::max<int64_t>(1, ceil_div(nnz, kStripNnz));
+    const int64_t work = nnz + n_rows * kRowCost;
+    p->strip_nnz = strip_nnz_for(work);
+    p->n_strips = std::max<int64_t>(1, ceil_div(work, p->strip_nnz));
     p->strip_row = nullptr;
     for (int t = 0; t < 2; ++t) {
         p->table[t].n_long = p->table[t].n_chunks = 0;
@@ -670,8 +687,8 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
     } while (0)
     PLAN_TRY(hipGetDevice(&p->device));
     PLAN_TRY(hipMalloc(&p->strip_row, (size_t)(p->n_strips + 1) * sizeof(int32_t)));
-    strip_rows_kernel<<<(unsigned)ceil_div(p->n_strips + 1, kBlock), kBlock, 0, st>>>(n_rows, indptr, p->n_strips,
-                                                                                      p->strip_row);
+    strip_rows_kernel<<<(unsigned)ceil_div(p->n_strips + 1, kBlock), kBlock, 0, st>>>(
+        n_rows, indptr, p->n_strips, p->strip_nnz, p->strip_row);
     PLAN_TRY(hipGetLastError());
     // rows longer than the smaller split threshold (at most nnz / (kSplitNarrow + 1) of them); the table
     // for the larger threshold is the subset of the same list

@@ -374,7 +374,7 @@ def dropout(x, keep_prob, seed, stream_id, gate=None, index_offset=0):
     return y
 
 
-def gemm(a, b, trans_b=False, relu=False):
+def gemm(a, b, trans_b=False, relu=False, out=None):
     """``a @ b`` (or ``a @ b.T``) in float32 on the MFMA pipe."""
     _require_cuda(a, b)
     a, b = _rowmajor(a), _rowmajor(b)
@@ -382,7 +382,11 @@ def gemm(a, b, trans_b=False, relu=False):
     n = b.shape[0] if trans_b else b.shape[1]
     if (b.shape[1] if trans_b else b.shape[0]) != k:
         raise ValueError('shape mismatch in gemm')
-    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if out is None:
+        c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    else:
+        _check_out(out, m, n)
+        c = out
     _lib.call('gcn_gemm_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), 1 if trans_b else 0, _p(c), _ld(c),
               _lib.GCN_RELU if relu else 0, _stream())
     return c

@@ -160,3 +160,26 @@ def test_fused_addend_equals_product_then_add(oracle):
         assert torch.equal(fused, plain + _t(d))
         fused_relu = sparse.spmm_add(a, _t(b), _t(d), relu=True)
         assert torch.equal(fused_relu, torch.relu(plain + _t(d)))
+
+
+def test_graphed_propagation_replays_the_same_bits(oracle):
+    """A_hat^k X on PubMed recorded as one HIP graph: equal to the step-by-step products, on a
+    second input too (the replay reads the new contents of the recorded input buffer)."""
+    import torch
+    from gcn_amd import smoothing, sparse
+    fx = load_golden('pubmed_graph')
+    n = int(fx['n'])
+    a = sparse.DeviceCSR(n, n, torch.as_tensor(fx['ai_indptr'].astype(np.int64)).cuda(),
+                         torch.as_tensor(fx['ai_indices'].astype(np.int32)).cuda(),
+                         torch.as_tensor(fx['hat_values'].astype(np.float32)).cuda())
+    k, f = 8, 500
+    graphed = smoothing.GraphedPropagation(a, f, k)
+    for seed in (7, 8):
+        x = sparse.synthetic_dense(n, f, seed=seed)
+        assert torch.equal(graphed(x), smoothing.propagate(a, x, k))
+    smooth = smoothing.GraphedPropagation(a, f, 3, addend=True)
+    x = sparse.synthetic_dense(n, f, seed=9)
+    cur = torch.zeros_like(x)
+    for _ in range(3):
+        cur = sparse.spmm_add(a, cur, x)
+    assert torch.equal(smooth(x), cur)
