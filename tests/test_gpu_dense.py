@@ -27,7 +27,8 @@ def test_dense_dropout_bit_exact(oracle, keep_prob):
 
 
 @pytest.mark.parametrize('m,n,k', [(2708, 7, 16), (3327, 6, 16), (19717, 3, 16), (1000, 16, 1433), (513, 130, 257),
-                                   (4096, 512, 512), (1, 1, 1), (129, 33, 2)])
+                                   (4096, 512, 512), (1, 1, 1), (129, 33, 2), (300, 200, 17), (257, 64, 31),
+                                   (256, 256, 64), (384, 96, 48)])
 @pytest.mark.parametrize('trans_b', [False, True])
 def test_gemm_mfma_against_float64(oracle, m, n, k, trans_b):
     from gcn_amd import sparse
@@ -50,3 +51,27 @@ def test_gemm_identity_with_asymmetric_operand():
     b = torch.arange(n * 40, dtype=torch.float32, device='cuda').reshape(n, 40)
     out = sparse.gemm(torch.eye(n, device='cuda'), b)
     assert torch.equal(out, b)
+
+
+@pytest.mark.parametrize('trans_b', [False, True])
+def test_gemm_strided_and_unaligned_operands(oracle, trans_b):
+    """Operands that are column slices of wider matrices: row strides larger than the width, a base
+    address off the 16-byte grid (scalar loader) and on it (vector loader), output into a slice."""
+    import torch
+    from gcn_amd import sparse
+    m, n, k = 260, 136, 72
+    a = oracle.synthetic_dense(m, k, seed=51)
+    b = oracle.synthetic_dense(k, n, seed=52)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    for shift in (1, 4):
+        a_wide = torch.zeros((m, k + 12), dtype=torch.float32, device='cuda')
+        a_wide[:, shift:shift + k] = _t(a)
+        bsrc = np.ascontiguousarray(b.T) if trans_b else b
+        b_wide = torch.zeros((bsrc.shape[0], bsrc.shape[1] + 8), dtype=torch.float32, device='cuda')
+        b_wide[:, shift:shift + bsrc.shape[1]] = _t(bsrc)
+        c_wide = torch.full((m, n + 8), -7.0, dtype=torch.float32, device='cuda')
+        sparse.gemm(a_wide[:, shift:shift + k], b_wide[:, shift:shift + bsrc.shape[1]], trans_b=trans_b,
+                    out=c_wide[:, 4:4 + n])
+        got = c_wide.cpu().numpy()
+        assert np.abs(got[:, 4:4 + n] - ref).max() <= REL_TOL * np.abs(ref).max()
+        assert np.all(got[:, :4] == -7.0) and np.all(got[:, 4 + n:] == -7.0)      # nothing outside the slice

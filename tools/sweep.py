@@ -51,7 +51,7 @@ def width_sweep(out, scale, widths, reps):
     a = rmat_support(scale)
     n, nnz = a.n_rows, a.nnz
     out.append('\n## Product `A_hat . B`, R-MAT scale %d (N = %d, nnz = %d)\n' % (scale, n, nnz))
-    out.append('| F | median ms | min ms | bytes_min GB/s | %% of 8 TB/s | gathered GB/s | GFLOP/s |')
+    out.append('| F | median ms | min ms | bytes_min GB/s | % of 8 TB/s | gathered GB/s | GFLOP/s |')
     out.append('|---|---|---|---|---|---|---|')
     for f in widths:
         b = sparse.synthetic_dense(n, f, seed=7)
