@@ -29,7 +29,7 @@ __global__ void dropout_kernel(int64_t n_rows, int64_t f, const float* __restric
 // Block tile 128 x BN (BN = 32, 64, 128), 4 waves, K staged 32 deep through one LDS buffer; 35 KB of
 // LDS and ~110 VGPRs let 4 blocks share a CU, and it is the other blocks that cover a block's
 // barriers and its global-load latency (a second LDS buffer at half the occupancy measured the same
-// or slower).  The loads of tile t+1 go to registers before the MFMAs of tile t and to LDS after them.
+// or slower, a 256 x 128 tile at 2 blocks per CU 15 % slower).  The loads of tile t+1 go to registers before the MFMAs of tile t and to LDS after them.
 //  - A sits row-major in LDS as it does in memory (pitch 36 floats: conflict-free 128-bit reads and
 //    writes).  The MFMA wants, per lane, A[row = lane % 32][k = 2 s + lane / 32] at step s; instead
 //    lanes 0-31 take k = 0..15 of the stage and lanes 32-63 k = 16..31, so a lane reads 4
@@ -45,10 +45,8 @@ __global__ void dropout_kernel(int64_t n_rows, int64_t f, const float* __restric
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBM = 128;
-
 // kBK = 32, or 16 for products whose whole K fits 16 (hidden -> classes)
-template <int BN, bool TRANS_B, int kBK>
+template <int kBM, int BN, bool TRANS_B, int kBK>
 __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n, int64_t k,
                                                            const float* __restrict__ a, int64_t lda,
                                                            const float* __restrict__ b, int64_t ldb,
@@ -172,27 +170,37 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
     };
     const int kh = (lane >> 5) * (kBK / 2);  // this lane's half of the stage's k range
     const int l31 = lane & 31;
+    // fragments of 4 consecutive k steps: A as one 128-bit read per 32-row tile, B as 4 scalar reads per
+    // 32-column tile.  The fragments of group g+1 are requested before the 4 x MT x NT MFMAs of group g.
+    auto read_frags = [&](int kq, float4 (&av)[MT], float (&bv)[NT][4]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            av[i] = *reinterpret_cast<const float4*>(as + ((wm * MT + i) * 32 + l31) * kAPitch + kh + kq);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][e] = bs[(kh + kq + e) * kBPitch + (wn * NT + j) * 32 + l31];
+    };
+    auto mfma_group = [&](const float4 (&av)[MT], const float (&bv)[NT][4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float ax = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bv[j][e], acc[i][j], 0, 0, 0);
+            }
+    };
     auto compute = [&]() {
+        constexpr int kGroups = kBK / 8;
+        float4 av[2][MT];
+        float bv[2][NT][4];
+        read_frags(0, av[0], bv[0]);
 #pragma unroll
-        for (int kq = 0; kq < kBK / 2; kq += 4) {
-            float4 av[MT];
-            float bv[NT][4];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                av[i] = *reinterpret_cast<const float4*>(as + ((wm * MT + i) * 32 + l31) * kAPitch + kh + kq);
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[j][e] = bs[(kh + kq + e) * kBPitch + (wn * NT + j) * 32 + l31];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const float ax = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bv[j][e], acc[i][j], 0, 0, 0);
-                }
+        for (int g = 0; g < kGroups; ++g) {
+            if (g + 1 < kGroups) read_frags(4 * (g + 1), av[(g + 1) & 1], bv[(g + 1) & 1]);
+            mfma_group(av[g & 1], bv[g & 1]);
         }
     };
 
@@ -223,6 +231,24 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
         __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (interior) {
+        // no bounds tests and one running pointer per 32x32 tile: the guarded form below spends ~15
+        // VALU instructions per stored element, as much issue time as a tenth of a K = 512 tile's MFMAs
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float* cp = c + (m0 + (wm * MT + i) * 32 + 4 * (lane >> 5)) * ldc + n0 + (wn * NT + j) * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][j][e];
+                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    cp[0] = v;
+                    cp += ((e & 3) == 3) ? 5 * ldc : ldc;  // rows 0-3, 8-11, 16-19, 24-27 of this half-wave
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -240,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
         }
 }
 
-template <int BN>
+template <int kBM, int BN>
 static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
                        int trans_b, float* c, int64_t ldc, int relu, hipStream_t st) {
     const int64_t tiles_m = ceil_div(m, kBM), tiles_n = ceil_div(n, BN);
@@ -249,7 +275,7 @@ static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
     const int a_vec = (lda % 4 == 0) && (((uintptr_t)a & 15) == 0);
     const int b_vec = (ldb % 4 == 0) && (((uintptr_t)b & 15) == 0);
 #define GCN_GEMM_GO(TB, BK)                                                                                  \
-    gemm_mfma_kernel<BN, TB, BK><<<(unsigned)n_tiles, kBlock, 0, st>>>(m, n, k, a, lda, b, ldb, c, ldc, relu, a_vec, \
+    gemm_mfma_kernel<kBM, BN, TB, BK><<<(unsigned)n_tiles, kBlock, 0, st>>>(m, n, k, a, lda, b, ldb, c, ldc, relu, a_vec, \
                                                                        b_vec, tiles_m, tiles_n)
     if (k <= 16) {
         if (trans_b)
@@ -298,9 +324,9 @@ int gcn_gemm_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, c
     if (!c || (k > 0 && (!a || !b))) return fail(GCN_ERR_BAD_ARG, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int relu = (flags & GCN_RELU) ? 1 : 0;
-    if (n <= 32) return launch_gemm<32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
-    if (n <= 64) return launch_gemm<64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
-    return launch_gemm<128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
+    if (n <= 32) return launch_gemm<128, 32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
+    if (n <= 64) return launch_gemm<128, 64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
+    return launch_gemm<128, 128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
 }
 
 }  // extern "C"
