@@ -1,5 +1,7 @@
 // Dense pieces of the GCN layer: tf.nn.dropout (gcn/layers.py:185) and the feature transform
 // H.W (gcn/layers.py:32-33) on the float32 MFMA pipe of gfx950.
+#include <algorithm>
+
 #include "common.h"
 
 namespace gcn {
@@ -293,6 +295,184 @@ static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
     return GCN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// C[k x n] = A^T . G for A [m x k], G [m x n]: the weight gradient dW = H^T . dP of a layer
+// (the gradient of tf.matmul / tf.sparse_tensor_dense_matmul w.r.t. the weights, gcn/models.py:86).
+// The reduction runs over the m nodes, so both operands are read in their storage order: a stage is 32
+// rows of A (TM columns) and of G (BN columns), copied to LDS as they are, and lane (column l % 32,
+// half l / 32) feeds row 16 * half + s of the stage to MFMA step s.  The rows are cut into `splits`
+// ranges, one block per (tile, range); with more than one range the partial tiles go to the workspace
+// and reduce_splits_kernel adds them in range order, so the result does not depend on scheduling.
+// ------------------------------------------------------------------------------------------------
+template <int TM, int BN>
+__global__ __launch_bounds__(64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)))
+void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a, int64_t lda,
+                    const float* __restrict__ g, int64_t ldg, float* __restrict__ out, int64_t ldo,
+                    int64_t split_stride, int64_t rows_per_split, int vec_ok, int64_t tiles_n) {
+    constexpr int kTiles = (TM / 32) * (BN / 32);
+    constexpr int kWaves = kTiles > 4 ? 4 : kTiles;
+    constexpr int kThreads = 64 * kWaves;
+    constexpr int kWavesN = (BN / 32 >= 2 && kWaves >= 2) ? (TM == 32 ? kWaves : 2) : 1;
+    constexpr int kWavesM = kWaves / kWavesN;
+    constexpr int MT = TM / (32 * kWavesM), NT = BN / (32 * kWavesN);
+    constexpr int kRows = 32;
+    constexpr int kXPitch = TM + 4, kGPitch = BN + 4;
+    constexpr int kXPer = kRows * TM / 4 / kThreads, kGPer = kRows * BN / 4 / kThreads;
+    __shared__ __attribute__((aligned(16))) float xs[kRows * kXPitch];
+    __shared__ __attribute__((aligned(16))) float gs[kRows * kGPitch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / kWavesN, wn = wave % kWavesN;
+    const int64_t k0 = (blockIdx.x / tiles_n) * TM;  // first column of A = first row of C
+    const int64_t n0 = (blockIdx.x % tiles_n) * BN;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t r_end = (r_begin + rows_per_split < m) ? r_begin + rows_per_split : m;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    float4 rx[kXPer], rg[kGPer];
+    auto load_fast = [&](int64_t r0) {
+#pragma unroll
+        for (int p = 0; p < kXPer; ++p) {
+            const int u = tid + kThreads * p;
+            rx[p] = *reinterpret_cast<const float4*>(a + (r0 + u / (TM / 4)) * lda + k0 + (u % (TM / 4)) * 4);
+        }
+#pragma unroll
+        for (int p = 0; p < kGPer; ++p) {
+            const int u = tid + kThreads * p;
+            rg[p] = *reinterpret_cast<const float4*>(g + (r0 + u / (BN / 4)) * ldg + n0 + (u % (BN / 4)) * 4);
+        }
+    };
+    // edge tiles and the last rows: whole float4 units where they are in range and aligned (a narrow
+    // operand -- 16 hidden units, 7 classes -- makes every tile an edge tile), single elements elsewhere
+    auto guarded_unit = [&](const float* base, int64_t ld, int64_t gr, int64_t gc, int64_t limit) -> float4 {
+        if (gr >= r_end || gc >= limit) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float* src = base + gr * ld + gc;
+        if (vec_ok && gc + 4 <= limit) return *reinterpret_cast<const float4*>(src);
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = (gc + e < limit) ? src[e] : 0.0f;
+        return make_float4(t[0], t[1], t[2], t[3]);
+    };
+    auto load_guarded = [&](int64_t r0) {
+#pragma unroll
+        for (int p = 0; p < kXPer; ++p) {
+            const int u = tid + kThreads * p;
+            rx[p] = guarded_unit(a, lda, r0 + u / (TM / 4), k0 + (u % (TM / 4)) * 4, k);
+        }
+#pragma unroll
+        for (int p = 0; p < kGPer; ++p) {
+            const int u = tid + kThreads * p;
+            rg[p] = guarded_unit(g, ldg, r0 + u / (BN / 4), n0 + (u % (BN / 4)) * 4, n);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < kXPer; ++p) {
+            const int u = tid + kThreads * p;
+            *reinterpret_cast<float4*>(xs + (u / (TM / 4)) * kXPitch + (u % (TM / 4)) * 4) = rx[p];
+        }
+#pragma unroll
+        for (int p = 0; p < kGPer; ++p) {
+            const int u = tid + kThreads * p;
+            *reinterpret_cast<float4*>(gs + (u / (BN / 4)) * kGPitch + (u % (BN / 4)) * 4) = rg[p];
+        }
+    };
+    const int half = (lane >> 5) * (kRows / 2);
+    const int l31 = lane & 31;
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < kRows / 2; ++s) {
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = xs[(half + s) * kXPitch + (wm * MT + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = gs[(half + s) * kGPitch + (wn * NT + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const bool cols_inside = (k0 + TM <= k) && (n0 + BN <= n) && vec_ok;
+    const int64_t n_stages = (r_end > r_begin) ? (r_end - r_begin + kRows - 1) / kRows : 0;
+    const int64_t n_full = cols_inside ? (r_end - r_begin) / kRows : 0;
+    if (n_stages > 0) {
+        if (n_full > 0)
+            load_fast(r_begin);
+        else
+            load_guarded(r_begin);
+        store_tile();
+    }
+    __syncthreads();
+    int64_t t = 0;
+    for (; t + 1 < n_full; ++t) {
+        load_fast(r_begin + (t + 1) * kRows);
+        compute();
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+    }
+    for (; t < n_stages; ++t) {
+        if (t + 1 < n_stages) load_guarded(r_begin + (t + 1) * kRows);
+        compute();
+        __syncthreads();
+        if (t + 1 < n_stages) store_tile();
+        __syncthreads();
+    }
+    float* dst = out + (int64_t)blockIdx.y * split_stride;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int64_t gc = n0 + (wn * NT + j) * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gr = k0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (gr < k && gc < n) dst[gr * ldo + gc] = acc[i][j][e];
+            }
+        }
+}
+
+// C[k x n] = sum over the row ranges, in range order, of the partial products [splits][k x n]
+__global__ void reduce_splits_kernel(int64_t k, int64_t n, int64_t splits, const float* __restrict__ part,
+                                     float* __restrict__ c, int64_t ldc) {
+    const int64_t total = k * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int64_t p = 0; p < splits; ++p) s = __fadd_rn(s, part[p * total + i]);
+        c[(i / n) * ldc + (i % n)] = s;
+    }
+}
+
+struct TnShape {
+    int64_t tiles, tiles_n, splits, rows_per_split;
+    int tm, bn;
+};
+
+static TnShape tn_shape(int64_t m, int64_t n, int64_t k) {
+    TnShape s;
+    s.tm = k <= 32 ? 32 : 128;
+    s.bn = n <= 32 ? 32 : 128;
+    s.tiles_n = ceil_div(n, s.bn);
+    s.tiles = ceil_div(k, s.tm) * s.tiles_n;
+    // enough blocks to fill the chip several times over, at least 256 rows each, at most 256 MiB of partials
+    int64_t splits = ceil_div(4096, std::max<int64_t>(s.tiles, 1));
+    splits = std::min(splits, std::max<int64_t>(1, m / 256));
+    splits = std::min(splits, std::max<int64_t>(1, (256ll << 20) / std::max<int64_t>(k * n * 4, 1)));
+    splits = std::min<int64_t>(splits, 65535);
+    s.rows_per_split = align_up(ceil_div(std::max<int64_t>(m, 1), splits), 32);
+    s.splits = ceil_div(std::max<int64_t>(m, 1), s.rows_per_split);
+    return s;
+}
+
 }  // namespace gcn
 
 using namespace gcn;
@@ -327,6 +507,55 @@ int gcn_gemm_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, c
     if (n <= 32) return launch_gemm<128, 32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
     if (n <= 64) return launch_gemm<128, 64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
     return launch_gemm<128, 128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
+}
+
+int gcn_gemm_tn_workspace_bytes(int64_t m, int64_t n, int64_t k, size_t* bytes) {
+    if (!bytes) return fail(GCN_ERR_BAD_ARG, "bytes is null");
+    if (m < 0 || n < 0 || k < 0) return fail(GCN_ERR_BAD_ARG, "negative dimension");
+    const TnShape s = tn_shape(m, n, k);
+    *bytes = s.splits > 1 ? (size_t)s.splits * (size_t)k * (size_t)n * sizeof(float) : 0;
+    return GCN_OK;
+}
+
+int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* g, int64_t ldg,
+                    float* c, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream) {
+    if (m < 0 || n < 0 || k < 0) return fail(GCN_ERR_BAD_ARG, "negative dimension");
+    if (lda < k || ldg < n || ldc < n) return fail(GCN_ERR_BAD_ARG, "leading dimension too small");
+    if (k == 0 || n == 0) return GCN_OK;
+    if (!c || (m > 0 && (!a || !g))) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const TnShape s = tn_shape(m, n, k);
+    float* out = c;
+    int64_t ldo = ldc, split_stride = 0;
+    if (s.splits > 1) {
+        const size_t need = (size_t)s.splits * (size_t)k * (size_t)n * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return fail(GCN_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        out = (float*)workspace;
+        ldo = n;
+        split_stride = k * n;
+    }
+    const int vec_ok = (lda % 4 == 0) && (ldg % 4 == 0) && (((uintptr_t)a & 15) == 0) && (((uintptr_t)g & 15) == 0);
+    const dim3 grid((unsigned)s.tiles, (unsigned)s.splits);
+#define GCN_TN_GO(TM, BN)                                                                                          \
+    gemm_tn_kernel<TM, BN><<<grid, 64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)), 0, st>>>(           \
+        m, n, k, a, lda, g, ldg, out, ldo, split_stride, s.rows_per_split, vec_ok, s.tiles_n)
+    if (s.tm == 128 && s.bn == 128)
+        GCN_TN_GO(128, 128);
+    else if (s.tm == 128)
+        GCN_TN_GO(128, 32);
+    else if (s.bn == 128)
+        GCN_TN_GO(32, 128);
+    else
+        GCN_TN_GO(32, 32);
+#undef GCN_TN_GO
+    GCN_LAUNCH_CHECK();
+    if (s.splits > 1) {
+        const int64_t blocks = std::min<int64_t>(ceil_div(k * n, kBlock), 4096);
+        reduce_splits_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(k, n, s.splits, out, c, ldc);
+        GCN_LAUNCH_CHECK();
+    }
+    return GCN_OK;
 }
 
 }  // extern "C"

@@ -79,7 +79,7 @@ class _DropoutFn(torch.autograd.Function):
 
 class _GemmFn(torch.autograd.Function):
     """out = A . W on the MFMA kernel; dA = dOut . W^T on it too; dW = A^T . dOut (a [k x n]
-    reduction over all nodes) is left to the library GEMM behind torch.matmul."""
+    reduction over all nodes) on the transposed-left kernel."""
 
     @staticmethod
     def forward(ctx, a, w):
@@ -90,7 +90,7 @@ class _GemmFn(torch.autograd.Function):
     def backward(ctx, grad):
         a, w = ctx.saved_tensors
         ga = sparse.gemm(grad, w, trans_b=True) if ctx.needs_input_grad[0] else None
-        gw = torch.matmul(a.t(), grad) if ctx.needs_input_grad[1] else None
+        gw = sparse.gemm_tn(a, grad) if ctx.needs_input_grad[1] else None
         return ga, gw
 
 

@@ -390,3 +390,24 @@ def gemm(a, b, trans_b=False, relu=False, out=None):
     _lib.call('gcn_gemm_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), 1 if trans_b else 0, _p(c), _ld(c),
               _lib.GCN_RELU if relu else 0, _stream())
     return c
+
+
+def gemm_tn(a, g, out=None):
+    """``a.T @ g`` for row-major ``a`` [m x k] and ``g`` [m x n] without forming the transpose: the
+    weight gradient of a layer, a sum over all m nodes."""
+    _require_cuda(a, g)
+    a, g = _rowmajor(a), _rowmajor(g)
+    m, k = a.shape
+    if g.shape[0] != m:
+        raise ValueError('shape mismatch in gemm_tn')
+    n = g.shape[1]
+    if out is None:
+        out = torch.empty((k, n), dtype=torch.float32, device=a.device)
+    else:
+        _check_out(out, k, n)
+    nbytes = ctypes.c_size_t()
+    _lib.call('gcn_gemm_tn_workspace_bytes', m, n, k, ctypes.byref(nbytes))
+    ws = _workspace(nbytes.value, a.device) if nbytes.value else None
+    _lib.call('gcn_gemm_tn_f32', m, n, k, _p(a), _ld(a), _p(g), _ld(g), _p(out), _ld(out), _p(ws), nbytes.value,
+              _stream())
+    return out

@@ -197,6 +197,15 @@ int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, cons
 int gcn_gemm_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
                  int trans_b, float* c, int64_t ldc, int flags, void* stream);
 
+/* C[k x n] = A^T . G for A [m x k] and G [m x n], both row-major: the weight gradient
+ * dW = H^T . dP that tf.train.AdamOptimizer.minimize derives for tf.matmul and for
+ * tf.sparse_tensor_dense_matmul with a dense left operand (gcn/models.py:86, gcn/layers.py:28-34).
+ * The sum over the m rows is cut into ranges whose partial results go to the workspace and are added
+ * in range order (deterministic); query the size first (0 when one range is enough). */
+int gcn_gemm_tn_workspace_bytes(int64_t m, int64_t n, int64_t k, size_t* bytes);
+int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* g, int64_t ldg,
+                    float* c, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

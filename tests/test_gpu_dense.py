@@ -75,3 +75,26 @@ def test_gemm_strided_and_unaligned_operands(oracle, trans_b):
         got = c_wide.cpu().numpy()
         assert np.abs(got[:, 4:4 + n] - ref).max() <= REL_TOL * np.abs(ref).max()
         assert np.all(got[:, :4] == -7.0) and np.all(got[:, 4 + n:] == -7.0)      # nothing outside the slice
+
+
+@pytest.mark.parametrize('m,n,k', [(2708, 7, 16), (2708, 16, 1433), (19717, 3, 16), (100000, 256, 256), (1000, 130, 33),
+                                   (31, 5, 9), (1, 1, 1), (300000, 16, 200), (65, 128, 32)])
+def test_weight_gradient_product_against_float64(oracle, m, n, k):
+    """dW = H^T . dP (the reduction over the nodes), including shapes that split the rows over many
+    blocks, ragged edges in every dimension and operands that are slices of wider matrices."""
+    import torch
+    from gcn_amd import sparse
+    a = oracle.synthetic_dense(m, k, seed=61)
+    g = oracle.synthetic_dense(m, n, seed=62)
+    ref = a.astype(np.float64).T @ g.astype(np.float64)
+    tol = REL_TOL * max(np.abs(ref).max(), np.sqrt(m))          # float32 sums of m products
+    out = sparse.gemm_tn(_t(a), _t(g))
+    assert np.abs(out.cpu().numpy() - ref).max() <= tol
+    assert torch.equal(out, sparse.gemm_tn(_t(a), _t(g)))       # deterministic: fixed order of the partial sums
+    a_wide = torch.zeros((m, k + 5), dtype=torch.float32, device='cuda')
+    a_wide[:, 1:1 + k] = _t(a)
+    c_wide = torch.full((k, n + 3), 3.0, dtype=torch.float32, device='cuda')
+    sparse.gemm_tn(a_wide[:, 1:1 + k], _t(g), out=c_wide[:, 2:2 + n])
+    got = c_wide.cpu().numpy()
+    assert np.abs(got[:, 2:2 + n] - ref).max() <= tol
+    assert np.all(got[:, :2] == 3.0) and np.all(got[:, 2 + n:] == 3.0)

@@ -126,11 +126,31 @@ def gemm_shapes(out, reps, quick):
         torch.cuda.empty_cache()
 
 
+def weight_gradient_shapes(out, reps, quick):
+    out.append('\n## Weight gradient `gcn_gemm_tn_f32` (C[k x n] = A^T . G, sum over m nodes; HBM-bound: A and G once)\n')
+    out.append('| m | k | n | median ms | GB/s (A+G once) | % of 8 TB/s | TFLOP/s | torch.matmul(A.t(), G) ms |')
+    out.append('|---|---|---|---|---|---|---|---|')
+    shapes = [(1 << 24, 256, 256), (1 << 24, 256, 16), (1 << 24, 16, 8), (1 << 22, 512, 512), (1 << 22, 512, 16)]
+    if quick:
+        shapes = [(1 << 18, 256, 16)]
+    for m, k, n in shapes:
+        a = sparse.synthetic_dense(m, k, seed=3)
+        g = sparse.synthetic_dense(m, n, seed=4)
+        c = torch.empty((k, n), dtype=torch.float32, device='cuda')
+        med, _ = timed(lambda: sparse.gemm_tn(a, g, out=c), reps=reps)
+        ref, _ = timed(lambda: torch.matmul(a.t(), g, out=c), reps=reps)
+        byt = 4.0 * m * (k + n)
+        out.append('| %d | %d | %d | %.3f | %.0f | %.1f | %.1f | %.3f |' % (
+            m, k, n, med, byt / med / 1e6, 100 * byt / (med * 1e-3) / HBM_PEAK, 2.0 * m * n * k / med / 1e9, ref))
+        del a, g, c
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='gpurun_out/sweeps.md')
     ap.add_argument('--quick', action='store_true', help='small scales only (smoke run)')
-    ap.add_argument('--sections', default='widths,powers,gemm')
+    ap.add_argument('--sections', default='widths,powers,gemm,wgrad')
     args = ap.parse_args()
     reps = 5 if args.quick else 20
     out = ['# Sweeps on one MI355X (%s)' % time.strftime('%Y-%m-%d'), '',
@@ -149,6 +169,9 @@ def main():
     if 'gemm' in sections:
         gemm_shapes(out, reps, args.quick)
         print('gemm done', flush=True)
+    if 'wgrad' in sections:
+        weight_gradient_shapes(out, reps, args.quick)
+        print('wgrad done', flush=True)
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     with open(args.out, 'w') as fh:
         fh.write('\n'.join(out) + '\n')
