@@ -44,7 +44,7 @@ def parse_args():
                     help='N > 1: all-gather the whole of B instead of exchanging only the referenced rows')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
                     help='development only: every rank uses cuda:0 and the gloo backend')
-    ap.add_argument('--cpu-row-stride', type=int, default=64,
+    ap.add_argument('--cpu-row-stride', type=int, default=16,
                     help='the CPU baseline multiplies every k-th row of the same matrix')
     return ap.parse_args()
 
@@ -104,6 +104,38 @@ def planetoid_epoch_ms(name, epochs=60):
         test_acc, _, _, _ = driver.train(cfg, sess, 123)
     ms = [float(line.split('median')[1].split()[0]) for line in buf.getvalue().splitlines() if 'epoch ms' in line]
     return {'dataset': name, 'epoch_ms': ms[0] if ms else None, 'epochs': epochs, 'test_acc': float(test_acc)}
+
+
+def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, classes=16):
+    """One training step (forward + backward + Adam, train.py:203-205) of a 2-layer GCN
+    features -> hidden -> classes on the bench graph, rows sharded over the ranks."""
+    import torch
+    from gcn_amd.dist_train import ShardedGCN
+    r0, r1 = shard.row_begin, shard.row_end
+    rows = torch.arange(r0, r1, device=x_local.device)
+    labels = torch.nn.functional.one_hot((rows * 2654435761 >> 7) % classes, classes).to(torch.int32)
+    mask = (rows % 64 == 0).to(torch.int32)
+    del rows
+    model = ShardedGCN(shard, x_local.shape[1], [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
+                       seed=123)
+    for _ in range(warmup):
+        model.train_step(x_local, labels, mask)
+    if group_world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = model.train_step(x_local, labels, mask)
+    if group_world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    if group_world > 1:
+        t = torch.tensor([ms], dtype=torch.float64, device=x_local.device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms = float(t.item())
+    return {'ms': ms, 'loss': float(loss), 'layers': [int(x_local.shape[1]), hidden, classes], 'steps': steps,
+            'what': 'forward + backward + Adam, dropout 0.5, rows/%d' % group_world}
 
 
 def cpu_baseline(a, b_dev, c_dev, row_stride):
@@ -184,6 +216,8 @@ def main():
         a = sparse.DeviceCSR(n, n, indptr, indices, vals)
         c = torch.empty((n, f), dtype=torch.float32, device=dev)
         a.plan.set_timing(True)
+        shard = gdist.RowShardedCSR(n, n, 0, n, a, 0, 1)
+        b_local = b_full
 
         def step():
             sparse.spmm(a, b_full, out=c)
@@ -261,6 +295,19 @@ def main():
         t = line['roofline']['traffic']
         if t:
             line['hbm_measured_gbps'] = t / (row_ms * 1e-3) / 1e9
+    # GCN epoch on the same graph, every rank takes part
+    epoch = None
+    if not args.no_epoch:
+        a.plan.set_timing(False)
+        if world == 1:
+            del c
+        else:
+            del op
+        torch.cuda.empty_cache()
+        epoch = rmat_epoch_ms(shard, b_local, world)
+    if rank == 0:
+        if epoch is not None:
+            line['gcn_epoch_rmat'] = epoch
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

@@ -138,6 +138,7 @@ class HaloPlan(object):
         make = csr_factory or sparse.DeviceCSR
         self.compact = make(local.n_rows, int(needed.numel()), local.indptr, new_cols, local.values)
         self.n_needed = int(needed.numel())
+        self._identity = (not self._collective) and self.n_needed == shard.n_cols == local.n_rows
         self._buffers = {}
 
     def exchange(self, b_local, slot=0, async_op=False):
@@ -148,6 +149,8 @@ class HaloPlan(object):
         ``(rows, work)`` is returned and ``work.wait()`` orders the current stream after the
         exchange; RCCL runs it on its own stream, which is what lets it overlap a product enqueued
         after the call."""
+        if self._identity:                      # one rank and every column referenced: B itself
+            return (b_local, _Done) if async_op else b_local
         f = b_local.shape[1]
         bufs = self._buffers.get((f, slot))
         if bufs is None:
