@@ -214,15 +214,23 @@ class HaloSpmm(object):
         self.c_local = torch.empty((shard.local.n_rows, f), dtype=torch.float32, device=shard.local.device)
 
     def __call__(self, b_local, relu=False):
-        if len(self.ranges) == 1:
-            return self._spmm(self.compact, self.plan.exchange(b_local), relu=relu, out=self.c_local)
-        c0, c1 = self.ranges[0]
-        pending = self.plan.exchange(b_local[:, c0:c1], slot=0, async_op=True)
-        for i, (c0, c1) in enumerate(self.ranges):
-            rows, work = pending
-            if i + 1 < len(self.ranges):
-                n0, n1 = self.ranges[i + 1]
-                pending = self.plan.exchange(b_local[:, n0:n1], slot=(i + 1) & 1, async_op=True)
-            work.wait()
-            self._spmm(self.compact, rows, relu=relu, out=self.c_local[:, c0:c1], wide_split=self.f >= 128)
-        return self.c_local
+        return halo_product(self.plan, b_local, self.c_local, relu, self.ranges, self._spmm)
+
+
+def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None):
+    """out = A_local . B with the exchange of column range i+1 in flight during the product of range i."""
+    spmm = spmm or sparse.spmm
+    f = b_local.shape[1]
+    ranges = ranges or [(0, f)]
+    if len(ranges) == 1:
+        return spmm(plan.compact, plan.exchange(b_local), relu=relu, out=out)
+    c0, c1 = ranges[0]
+    pending = plan.exchange(b_local[:, c0:c1], slot=0, async_op=True)
+    for i, (c0, c1) in enumerate(ranges):
+        rows, work = pending
+        if i + 1 < len(ranges):
+            n0, n1 = ranges[i + 1]
+            pending = plan.exchange(b_local[:, n0:n1], slot=(i + 1) & 1, async_op=True)
+        work.wait()
+        spmm(plan.compact, rows, relu=relu, out=out[:, c0:c1], wide_split=f >= 128)
+    return out

@@ -11,16 +11,23 @@ import numpy as np
 import torch
 
 from . import graph, sparse
-from .dist import HaloPlan, all_reduce_sum
+from .dist import HaloPlan, all_reduce_sum, column_chunks, halo_product
 from .layers import _GemmFn
 from .models import TfAdam
 
 
+def _product(plan, b_local, relu, chunks):
+    """A_local . exchange(B) into a fresh tensor; wide operands pipeline the exchange over column ranges."""
+    out = torch.empty((plan.compact.n_rows, b_local.shape[1]), dtype=torch.float32, device=b_local.device)
+    ranges = column_chunks(b_local.shape[1], chunks if b_local.shape[1] >= 128 else 1)
+    return halo_product(plan, b_local, out, relu, ranges)
+
+
 class _HaloSpmmFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, b_local, fuse_relu):
-        out = sparse.spmm(plan.compact, plan.exchange(b_local), relu=fuse_relu)
-        ctx.plan, ctx.fuse_relu = plan, fuse_relu
+    def forward(ctx, plan, b_local, fuse_relu, chunks):
+        out = _product(plan, b_local, fuse_relu, chunks)
+        ctx.plan, ctx.fuse_relu, ctx.chunks = plan, fuse_relu, chunks
         if fuse_relu:
             ctx.save_for_backward(out)
         return out
@@ -32,7 +39,7 @@ class _HaloSpmmFn(torch.autograd.Function):
             grad = sparse.dropout(grad, 1.0, 0, 0, gate=out)
         plan = ctx.plan
         # symmetric support: rows of A^T are rows of A
-        return None, sparse.spmm(plan.compact, plan.exchange(grad.contiguous())), None
+        return None, _product(plan, grad.contiguous(), False, ctx.chunks), None, None
 
 
 class _ShardDropoutFn(torch.autograd.Function):
@@ -51,8 +58,9 @@ class ShardedGCN(object):
     """Dense-feature GCN (connection 'c' * L) over a ``RowShardedCSR`` with a symmetric support."""
 
     def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
-                 seed=0, group=None):
+                 seed=0, group=None, chunks=4):
         self.shard, self.group = shard, group
+        self.chunks = chunks if shard.world > 1 else 1      # ranges of feature columns an exchange is pipelined over
         self.plan = HaloPlan(shard, group=group)
         self.dropout, self.wd, self.seed = float(dropout), float(weight_decay), int(seed)
         sizes = [f_in] + list(layer_size) + [n_classes]
@@ -81,7 +89,7 @@ class ShardedGCN(object):
                 offset = self.shard.row_begin * h.shape[1]
                 h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64 + li, offset)
             p = _GemmFn.apply(h, w)
-            h = _HaloSpmmFn.apply(self.plan, p, li != last)
+            h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks)
         return h
 
     def loss_terms(self, logits, labels_local, mask_local):

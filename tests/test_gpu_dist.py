@@ -116,7 +116,7 @@ def _train_worker(rank, world, port, result_dir, scale, steps):
     try:
         from gcn_amd import dist as gdist, sparse
         from gcn_amd.dist_train import ShardedGCN
-        n, f_in, classes = 1 << scale, 32, 8
+        n, f_in, classes, hidden = 1 << scale, 32, 8, 128
         indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
         d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
         vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
@@ -127,7 +127,7 @@ def _train_worker(rank, world, port, result_dir, scale, steps):
         cls = torch.randint(0, classes, (n,), generator=gen)
         labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32)[r0:r1].cuda()
         mask = (torch.rand(n, generator=gen) < 0.05).to(torch.int32)[r0:r1].cuda()
-        model = ShardedGCN(shard, f_in, [16], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9)
+        model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9)
         losses = [float(model.train_step(x, labels, mask)) for _ in range(steps)]
         if rank == 0:
             np.save(os.path.join(result_dir, 'loss_w%d.npy' % world), np.array(losses))
