@@ -85,7 +85,7 @@ def measured_traffic(kernel, scale, edge_factor, f, world):
     return None
 
 
-def planetoid_epoch_ms(name, epochs=60):
+def planetoid_epoch_ms(name, epochs=60, hip_graph=False):
     """Median wall time of one optimiser step (forward + backward + Adam: the region the reference
     times at train.py:203-205) of the 2-layer GCN on a Planetoid dataset, 20 labels per class."""
     import contextlib
@@ -93,7 +93,8 @@ def planetoid_epoch_ms(name, epochs=60):
     import train as driver
     from config import load_configuration
     from gcn_amd import graph as tf
-    configuration, args = load_configuration(['--dataset', name, '--train_size', '20'], echo=False)
+    configuration, args = load_configuration(['--dataset', name, '--train_size', '20'] +
+                                             (['--hip_graph'] if hip_graph else []), echo=False)
     driver.args = args
     cfg = configuration['model_list'][0]
     cfg['epochs'] = epochs
@@ -103,7 +104,8 @@ def planetoid_epoch_ms(name, epochs=60):
     with contextlib.redirect_stdout(buf), tf.Session() as sess:
         test_acc, _, _, _ = driver.train(cfg, sess, 123)
     ms = [float(line.split('median')[1].split()[0]) for line in buf.getvalue().splitlines() if 'epoch ms' in line]
-    return {'dataset': name, 'epoch_ms': ms[0] if ms else None, 'epochs': epochs, 'test_acc': float(test_acc)}
+    return {'dataset': name, 'epoch_ms': ms[0] if ms else None, 'epochs': epochs, 'test_acc': float(test_acc),
+            'train_step': 'one HIP graph' if hip_graph else 'eager launches'}
 
 
 def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, classes=16):
@@ -291,7 +293,8 @@ def main():
             line['cpu_baseline_all_cores'] = allcores
             line['parity_sample'] = check
         if world == 1 and not args.no_epoch:
-            line['gcn_epoch'] = [planetoid_epoch_ms('cora'), planetoid_epoch_ms('citeseer')]
+            line['gcn_epoch'] = [planetoid_epoch_ms('cora'), planetoid_epoch_ms('citeseer'),
+                                 planetoid_epoch_ms('cora', hip_graph=True), planetoid_epoch_ms('citeseer', hip_graph=True)]
         t = line['roofline']['traffic']
         if t:
             line['hbm_measured_gbps'] = t / (row_ms * 1e-3) / 1e9

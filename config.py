@@ -52,6 +52,8 @@ def build_parser():
     parser.add_argument('--dataset', type=str)
     parser.add_argument('--train_size', type=str)
     parser.add_argument('--repeating', type=int)
+    parser.add_argument('--hip_graph', action='store_true',
+                        help='record the train step once as a HIP graph and replay it (not a flag of the reference)')
     return parser
 
 
@@ -67,6 +69,8 @@ def load_configuration(argv=None, echo=True):
         configuration['default']['train_size'] = ast.literal_eval(args.train_size)
     if args.repeating is not None:
         configuration['repeating'] = args.repeating
+    if args.hip_graph:
+        configuration['default']['hip_graph'] = True
     if echo:
         print(args)
         pprint.PrettyPrinter(indent=4).pprint(configuration)

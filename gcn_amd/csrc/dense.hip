@@ -13,7 +13,9 @@ constexpr int kBlock = 256;
 // ------------------------------------------------------------------------------------------------
 __global__ void dropout_kernel(int64_t n_rows, int64_t f, const float* __restrict__ x, int64_t ldx,
                                const float* __restrict__ gate, int64_t ldg, float* __restrict__ y, int64_t ldy,
-                               float keep_prob, uint64_t key, uint64_t index_offset) {
+                               float keep_prob, uint64_t key, uint64_t index_offset,
+                               const uint64_t* __restrict__ stream_offset, uint64_t seed, uint64_t stream_id) {
+    if (stream_offset) key = stream_key(seed, stream_id + *stream_offset);  // per replay of a recorded launch
     const int64_t total = n_rows * f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / f, c = i - r * f;
@@ -463,9 +465,10 @@ static TnShape tn_shape(int64_t m, int64_t n, int64_t k) {
     s.bn = n <= 32 ? 32 : 128;
     s.tiles_n = ceil_div(n, s.bn);
     s.tiles = ceil_div(k, s.tm) * s.tiles_n;
-    // enough blocks to fill the chip several times over, at least 256 rows each, at most 256 MiB of partials
+    // enough blocks to fill the chip several times over, at least 64 rows each (on a small graph the
+    // stages of a block are a latency chain: better many short blocks), at most 256 MiB of partials
     int64_t splits = ceil_div(4096, std::max<int64_t>(s.tiles, 1));
-    splits = std::min(splits, std::max<int64_t>(1, m / 256));
+    splits = std::min(splits, std::max<int64_t>(1, m / 64));
     splits = std::min(splits, std::max<int64_t>(1, (256ll << 20) / std::max<int64_t>(k * n * 4, 1)));
     splits = std::min<int64_t>(splits, 65535);
     s.rows_per_split = align_up(ceil_div(std::max<int64_t>(m, 1), splits), 32);
@@ -480,8 +483,8 @@ using namespace gcn;
 extern "C" {
 
 int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, const float* gate, int64_t ldg, float* y,
-                    int64_t ldy, float keep_prob, uint64_t seed, uint64_t stream_id, uint64_t index_offset,
-                    void* stream) {
+                    int64_t ldy, float keep_prob, uint64_t seed, uint64_t stream_id, const uint64_t* stream_offset,
+                    uint64_t index_offset, void* stream) {
     if (n_rows < 0 || f < 0 || ldx < f || ldy < f || (gate && ldg < f)) return fail(GCN_ERR_BAD_ARG, "bad shape");
     if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
     const int64_t total = n_rows * f;
@@ -490,7 +493,8 @@ int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, cons
     int64_t blocks = ceil_div(total, kBlock);
     if (blocks > 256 * 32) blocks = 256 * 32;
     dropout_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_rows, f, x, ldx, gate, ldg, y, ldy,
-                                                                        keep_prob, stream_key(seed, stream_id), index_offset);
+                                                                        keep_prob, stream_key(seed, stream_id), index_offset,
+                                                                        stream_offset, seed, stream_id);
     GCN_LAUNCH_CHECK();
     return GCN_OK;
 }

@@ -58,7 +58,12 @@ constexpr int kSplitNarrow = 256;   // lane groups narrower than a wave: every w
 constexpr int kSplitWide = 1024;    // one wave per row
 static inline int split_of(int table) { return table == 0 ? kSplitNarrow : kSplitWide; }
 constexpr int kBlock = 256;
-constexpr int kUnroll = 4;
+constexpr int kUnroll = 4;       // entries in flight per lane group
+// A matrix too small to fill the chip finishes when its longest row does: that row's entries are a
+// chain of dependent batches walked by one lane group.  Narrow operands then take 16 entries per
+// batch (same order of additions, same bits; the extra loads of short rows hit the clamped, cached
+// address).  Cora, F = 16: 29 -> 12 us per product.
+constexpr int kUnrollSmall = 16;
 
 // ------------------------------------------------------------------------------------------------
 // plan kernels
@@ -143,6 +148,10 @@ struct DropArgs {
     uint64_t key;
     float keep_prob;
     float inv_keep;
+    // when stream_offset is set the kernel derives the key itself from (seed, stream_id + *stream_offset):
+    // a launch recorded in a HIP graph then draws a new mask on every replay
+    const uint64_t* stream_offset;
+    uint64_t seed, stream_id;
 };
 
 // acc += sum over entries k0..k1-1 (in order) of a_k * B[col_k, this lane's columns].
@@ -275,7 +284,7 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
 
 // rows of ordinary length, narrow dense operand: a wave owns 64/LPR consecutive strips; each lane
 // group takes the next unclaimed row of that range when it has finished its own
-template <int LPR, int VEC, int VPL, bool DROPOUT>
+template <int LPR, int VEC, int VPL, bool DROPOUT, int kUnroll>
 __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, const int32_t* __restrict__ strip_row,
                                             const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                             const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
@@ -439,7 +448,7 @@ struct PlanView {
 
 // The whole product in one launch: the blocks that sum chunks of long rows come first (they are
 // the longest work items), the strip blocks after them.
-template <int LPR, int VEC, int VPL, bool DROPOUT>
+template <int LPR, int VEC, int VPL, bool DROPOUT, int U>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const int64_t* __restrict__ indptr,
                                                            const int32_t* __restrict__ indices,
                                                            const float* __restrict__ vals, int64_t f,
@@ -448,6 +457,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
                                                            float* __restrict__ part, int64_t ldp, int relu,
                                                            DropArgs dr, const float* __restrict__ add,
                                                            int64_t ldadd) {
+    if (DROPOUT && dr.stream_offset) dr.key = stream_key(dr.seed, dr.stream_id + *dr.stream_offset);
     const int64_t block = blockIdx.x;
     if (block < pv.chunk_blocks)
         chunks_block<LPR, VEC, VPL, DROPOUT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
         strips_block<LPR, VEC, VPL, DROPOUT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
                                              vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd);
     else
-        slots_block<LPR, VEC, VPL, DROPOUT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
+        slots_block<LPR, VEC, VPL, DROPOUT, U>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
                                             vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd);
 }
 
@@ -537,7 +547,7 @@ struct SpmmCall {
     hipStream_t st;
 };
 
-template <int LPR, int VEC, int VPL, bool DROPOUT>
+template <int LPR, int VEC, int VPL, bool DROPOUT, int U = kUnroll>
 static int launch_variant(const SpmmCall& a) {
     const gcn_spmm_plan* p = a.plan;
     constexpr int kWaves = kBlock / 64;
@@ -557,7 +567,7 @@ static int launch_variant(const SpmmCall& a) {
     const int64_t grid = pv.chunk_blocks + ceil_div(strip_waves, kWaves);
     if (grid > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[0], a.st));
-    spmm_rows_kernel<LPR, VEC, VPL, DROPOUT><<<(unsigned)grid, kBlock, 0, a.st>>>(
+    spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U><<<(unsigned)grid, kBlock, 0, a.st>>>(
         pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add, a.ldadd);
     GCN_LAUNCH_CHECK();
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[1], a.st));
@@ -575,6 +585,13 @@ static int launch_variant(const SpmmCall& a) {
 template <int VEC, bool DROPOUT>
 static int launch_by_width(const SpmmCall& a) {
     const int64_t nvec = ceil_div(a.f, VEC);
+    if (a.plan->strip_nnz < kStripNnz && nvec <= 16) {  // small matrix, narrow operand
+        if (nvec <= 1) return launch_variant<1, VEC, 1, DROPOUT, kUnrollSmall>(a);
+        if (nvec <= 2) return launch_variant<2, VEC, 1, DROPOUT, kUnrollSmall>(a);
+        if (nvec <= 4) return launch_variant<4, VEC, 1, DROPOUT, kUnrollSmall>(a);
+        if (nvec <= 8) return launch_variant<8, VEC, 1, DROPOUT, kUnrollSmall>(a);
+        return launch_variant<16, VEC, 1, DROPOUT, kUnrollSmall>(a);
+    }
     if (nvec <= 1) return launch_variant<1, VEC, 1, DROPOUT>(a);
     if (nvec <= 2) return launch_variant<2, VEC, 1, DROPOUT>(a);
     if (nvec <= 4) return launch_variant<4, VEC, 1, DROPOUT>(a);
@@ -826,9 +843,10 @@ int gcn_spmm_csr_add_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const
 int gcn_spmm_csr_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
                              const float* vals, const int64_t* perm, int64_t f, const float* b, int64_t ldb, float* c,
                              int64_t ldc, int flags, float keep_prob, uint64_t seed, uint64_t stream_id,
+                             const uint64_t* stream_offset,
                              void* workspace, size_t workspace_bytes, void* stream) {
     if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
-    DropArgs dr = {perm, stream_key(seed, stream_id), keep_prob, 1.0f / keep_prob};
+    DropArgs dr = {perm, stream_key(seed, stream_id), keep_prob, 1.0f / keep_prob, stream_offset, seed, stream_id};
     return spmm_entry<true>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
                             stream);
 }

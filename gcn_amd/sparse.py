@@ -344,6 +344,30 @@ def row_normalize(indptr, vals):
     return out
 
 
+# When set (a 1-element int64 device tensor), the dropout kernels add its value to the stream id at
+# run time: launches recorded in a HIP graph then draw new masks on every replay.
+_stream_offset = None
+
+
+class stream_offset(object):
+    """Context manager: dropout launches inside it take their stream id offset from ``tensor``."""
+
+    def __init__(self, tensor):
+        if tensor is not None and (not tensor.is_cuda or tensor.dtype != torch.int64 or tensor.numel() != 1):
+            raise ValueError('stream offset must be a 1-element int64 device tensor')
+        self.tensor = tensor
+
+    def __enter__(self):
+        global _stream_offset
+        self.previous, _stream_offset = _stream_offset, self.tensor
+        return self.tensor
+
+    def __exit__(self, *exc):
+        global _stream_offset
+        _stream_offset = self.previous
+        return False
+
+
 def spmm_dropout(a, b, keep_prob, seed, stream_id, relu=False, out=None):
     """``sparse_dropout(a, keep_prob) @ b`` with the dropout fused into the product.
     Entry ids for the random stream come from ``a.perm`` when ``a`` is a transposed copy."""
@@ -357,7 +381,7 @@ def spmm_dropout(a, b, keep_prob, seed, stream_id, relu=False, out=None):
     ws, ws_bytes = a.plan.workspace(f, b.device)
     _lib.call('gcn_spmm_csr_dropout_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), _p(a.perm), f,
               _p(b), _ld(b), _p(out), _ld(out), _lib.GCN_RELU if relu else 0, float(keep_prob), int(seed),
-              int(stream_id), _p(ws), ws_bytes, _stream())
+              int(stream_id), _p(_stream_offset), _p(ws), ws_bytes, _stream())
     return out
 
 
@@ -370,7 +394,8 @@ def dropout(x, keep_prob, seed, stream_id, gate=None, index_offset=0):
         gate = _rowmajor(gate)
     y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
     _lib.call('gcn_dropout_f32', x.shape[0], x.shape[1], _p(x), _ld(x), _p(gate), 0 if gate is None else _ld(gate),
-              _p(y), _ld(y), float(keep_prob), int(seed), int(stream_id), int(index_offset), _stream())
+              _p(y), _ld(y), float(keep_prob), int(seed), int(stream_id), _p(_stream_offset), int(index_offset),
+              _stream())
     return y
 
 

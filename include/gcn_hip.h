@@ -166,11 +166,14 @@ int gcn_spmm_csr_add_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const
  * entry k is kept iff floor(keep_prob + u_k) == 1 in float32 and then scaled by
  * float32(1/keep_prob); u_k is the counter-based uniform of entry id
  * (perm ? perm[k] : k) in stream (seed, stream_id).  perm lets a transposed
- * copy of X reproduce the mask of the original feed order. */
+ * copy of X reproduce the mask of the original feed order.  stream_offset (device pointer, may be
+ * NULL): the 64-bit value it points to is added to stream_id when the kernel runs, so that a launch
+ * recorded in a HIP graph draws a new mask on every replay (the caller updates the value between
+ * replays, as sess.run draws new noise on every call). */
 int gcn_spmm_csr_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
                              const float* vals, const int64_t* perm, int64_t f, const float* b, int64_t ldb, float* c,
                              int64_t ldc, int flags, float keep_prob, uint64_t seed, uint64_t stream_id,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             const uint64_t* stream_offset, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Dense pieces of the layer.                                                 *
@@ -186,10 +189,11 @@ int gcn_row_normalize(int64_t n_rows, int64_t nnz, const int64_t* indptr, const 
 /* y = (x / keep_prob) * floor(keep_prob + u): tf.nn.dropout at gcn/layers.py:185.
  * gate (may be NULL): additionally y = 0 where gate <= 0 (ReLU backward).
  * Element (r, c) draws the uniform of id index_offset + r * f + c: a rank that holds the rows
- * [r0, r1) of a larger matrix passes r0 * f and gets the mask of the unsplit matrix. */
+ * [r0, r1) of a larger matrix passes r0 * f and gets the mask of the unsplit matrix.
+ * stream_offset: as for gcn_spmm_csr_dropout_f32. */
 int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, const float* gate, int64_t ldg, float* y,
-                    int64_t ldy, float keep_prob, uint64_t seed, uint64_t stream_id, uint64_t index_offset,
-                    void* stream);
+                    int64_t ldy, float keep_prob, uint64_t seed, uint64_t stream_id, const uint64_t* stream_offset,
+                    uint64_t index_offset, void* stream);
 
 /* C[m x n] = A . op(B) in float32 on the f32 MFMA pipe: tf.matmul at
  * gcn/layers.py:32-33 (H . W).  A is [m x k]; trans_b = 0: B is [k x n];

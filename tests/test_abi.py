@@ -53,7 +53,7 @@ def test_status_codes_map_to_the_reference_exception_types():
     assert lib.gcn_spmm_plan_create(-1, 1, 0, None, ctypes.byref(ctypes.c_void_p()), None) == _lib.GCN_ERR_BAD_ARG
     assert b'bad shape' in lib.gcn_last_error_string()
     assert lib.gcn_gemm_f32(4, 4, 4, None, 2, None, 4, 0, None, 4, 0, None) == _lib.GCN_ERR_BAD_ARG
-    assert lib.gcn_dropout_f32(4, 4, None, 4, None, 0, None, 4, 0.0, 1, 1, 0, None) == _lib.GCN_ERR_BAD_ARG
+    assert lib.gcn_dropout_f32(4, 4, None, 4, None, 0, None, 4, 0.0, 1, 1, None, 0, None) == _lib.GCN_ERR_BAD_ARG
 
 
 def test_product_fails_loudly_without_a_gpu():

@@ -180,3 +180,47 @@ def test_driver_reaches_the_expected_accuracy(name, floor, capsys):
     assert prediction.shape[1] == len(test_acc_of_class)
     assert np.allclose(prediction.sum(1), 1.0, atol=1e-5)
     assert 'Optimization Finished!' in capsys.readouterr().out
+
+
+def test_recorded_train_step_follows_the_eager_one():
+    """The train step replayed from a HIP graph (dropout stream offset and Adam step size read from
+    device memory) against the step launched kernel by kernel, on Cora with dropout 0.5: the masks are
+    the same, so loss and accuracy agree step for step and the weights to rounding of the Adam update."""
+    from config import load_configuration
+    from gcn_amd import graph as tf, models, utils
+
+    def trajectory(extra, steps=6):
+        configuration, _ = load_configuration(['--dataset', 'cora', '--train_size', '20'] + extra, echo=False)
+        cfg = configuration['model_list'][0]
+        np.random.seed(123)
+        tf.set_random_seed(123)
+        adj, features, y_train, _, _, train_mask, _, _ = utils.load_data(
+            'cora', train_size=20, validation_size=500, model_config=cfg, shuffle=True)
+        support = [utils.preprocess_adj(adj)]
+        if not isinstance(features, tuple):
+            features = utils.sparse_to_tuple(utils.preprocess_features(features, 'bow'))
+        placeholders = {
+            'support': [tf.sparse_placeholder(tf.float32, name='support_0')],
+            'features': tf.sparse_placeholder(tf.float32, name='features'),
+            'labels': tf.placeholder(tf.int32, shape=(None, y_train.shape[1]), name='labels'),
+            'labels_mask': tf.placeholder(tf.int32, name='labels_mask'),
+            'dropout': tf.placeholder_with_default(0., shape=(), name='dropout'),
+            'num_features_nonzero': tf.placeholder(tf.int32, name='num_features_nonzero')}
+        model = models.GCN_MLP(cfg, placeholders, input_dim=features[2][1])
+        feed = utils.construct_feed_dict(features, support, y_train, train_mask, placeholders)
+        feed.update({placeholders['dropout']: 0.5})
+        sess = tf.Session()
+        seen = []
+        for _ in range(steps):
+            _, loss, acc = sess.run([model.opt_op, model.loss, model.accuracy], feed_dict=feed)
+            seen.append((float(loss), float(acc)))
+            sess.run([model.loss, model.accuracy], feed_dict=feed)      # an eager run between replays, as train.py makes
+        return np.array(seen), [v.detach().cpu().numpy() for v in model._trainable()], model
+
+    eager, w_eager, _ = trajectory([])
+    recorded, w_recorded, model = trajectory(['--hip_graph'])
+    assert len(model._recorded) == 1                                     # one capture, replayed
+    assert np.allclose(eager, recorded, rtol=1e-5, atol=1e-6)
+    assert eager[-1, 0] < eager[0, 0]
+    for a, b in zip(w_eager, w_recorded):
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max()
