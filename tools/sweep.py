@@ -146,11 +146,36 @@ def weight_gradient_shapes(out, reps, quick):
         torch.cuda.empty_cache()
 
 
+def sparse_feature_layer(out, reps, quick):
+    out.append('\n## First layer on sparse features: `sparse_dropout(X) . W0` fused (bag-of-words X, 50 entries per row, 4096 columns; W0 4096 x F)\n')
+    out.append('| rows | nnz(X) | F | dropout | median ms | CSR bytes GB/s (8 nnz + 8 N + 4 N F) | gathered GB/s |')
+    out.append('|---|---|---|---|---|---|---|')
+    n = 1 << (16 if quick else 22)
+    per_row, f_in = 50, 4096
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    indices = torch.randint(0, f_in, (n, per_row), generator=gen, device='cuda', dtype=torch.int32).sort(dim=1).values.reshape(-1)
+    indptr = torch.arange(n + 1, device='cuda', dtype=torch.int64) * per_row
+    vals = torch.rand(n * per_row, generator=gen, device='cuda')
+    x = sparse.DeviceCSR(n, f_in, indptr, indices, vals)
+    for f in (16, 64):
+        w = sparse.synthetic_dense(f_in, f, seed=5)
+        c = torch.empty((n, f), dtype=torch.float32, device='cuda')
+        for keep in (1.0, 0.5):
+            if keep < 1.0:
+                med, _ = timed(lambda: sparse.spmm_dropout(x, w, keep, 7, 3, out=c), reps=reps)
+            else:
+                med, _ = timed(lambda: sparse.spmm(x, w, out=c), reps=reps)
+            byt = 8.0 * x.nnz + 8.0 * n + 4.0 * n * f
+            gat = 8.0 * x.nnz + 8.0 * n + 4.0 * f * x.nnz + 4.0 * n * f
+            out.append('| %d | %d | %d | %s | %.3f | %.0f | %.0f |' % (n, x.nnz, f, 'keep 0.5' if keep < 1 else 'off', med,
+                                                                     byt / med / 1e6, gat / med / 1e6))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='gpurun_out/sweeps.md')
     ap.add_argument('--quick', action='store_true', help='small scales only (smoke run)')
-    ap.add_argument('--sections', default='widths,powers,gemm,wgrad')
+    ap.add_argument('--sections', default='widths,powers,gemm,wgrad,features')
     args = ap.parse_args()
     reps = 5 if args.quick else 20
     out = ['# Sweeps on one MI355X (%s)' % time.strftime('%Y-%m-%d'), '',
@@ -169,6 +194,9 @@ def main():
     if 'gemm' in sections:
         gemm_shapes(out, reps, args.quick)
         print('gemm done', flush=True)
+    if 'features' in sections:
+        sparse_feature_layer(out, reps, args.quick)
+        print('features done', flush=True)
     if 'wgrad' in sections:
         weight_gradient_shapes(out, reps, args.quick)
         print('wgrad done', flush=True)
