@@ -325,6 +325,20 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
         for (int v = 0; v < VPL; ++v)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
+        // (column, value, entry id) of the batch at k: loaded when the row is taken, and for the next
+        // batch while the B rows of the current one are in flight
+        uint32_t cidx[kUnroll];
+        float a[kUnroll];
+        uint64_t id[kUnroll];
+        auto fetch_batch = [&](int64_t kb, int64_t k_last) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
+                cidx[u] = (uint32_t)indices[ku];
+                a[u] = vals[ku];
+                if (DROPOUT) id[u] = dr.perm ? (uint64_t)dr.perm[ku] : (uint64_t)ku;
+            }
+        };
         for (;;) {
             const bool idle = live && (k >= k1);
             const uint64_t m = __ballot(idle) & leaders;
@@ -339,10 +353,13 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                 if (rn < r_hi) {
                     const int64_t a0 = indptr[rn];
                     const int64_t a1 = indptr[rn + 1];
-                    if (a1 - a0 <= split) {  // longer rows are summed chunk-wise
+                    if (a1 - a0 <= split && a1 > a0) {  // longer rows are summed chunk-wise
                         r = rn;
                         k = a0;
                         k1 = a1;
+                        fetch_batch(a0, a1 - 1);
+                    } else if (a1 == a0) {
+                        r = rn;  // empty row: stored as zeros (or the addend) on the next turn
                     }
 #pragma unroll
                     for (int v = 0; v < VPL; ++v)
@@ -357,21 +374,6 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
             if (k < k1) {
                 const int64_t k_last = k1 - 1;
                 const int64_t rem = k1 - k;
-                uint32_t cidx[kUnroll];
-                float a[kUnroll];
-                bool kept[kUnroll];
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-                    const int64_t ku = (k + u < k_last) ? k + u : k_last;
-                    cidx[u] = (uint32_t)indices[ku];
-                    a[u] = vals[ku];
-                    kept[u] = true;
-                    if (DROPOUT) {
-                        const uint64_t id = dr.perm ? (uint64_t)dr.perm[ku] : (uint64_t)ku;
-                        kept[u] = keep_entry(dr.key, id, dr.keep_prob);
-                        a[u] = __fmul_rn(a[u], dr.inv_keep);
-                    }
-                }
                 float bv[kUnroll][VPL][VEC];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
@@ -379,6 +381,19 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
 #pragma unroll
                     for (int v = 0; v < VPL; ++v) load_vec<VEC>(brow + lcol[v], bv[u][v]);
                 }
+                float a_now[kUnroll];
+                bool kept[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    a_now[u] = a[u];
+                    kept[u] = true;
+                    if (DROPOUT) {
+                        kept[u] = keep_entry(dr.key, id[u], dr.keep_prob);
+                        a_now[u] = __fmul_rn(a[u], dr.inv_keep);
+                    }
+                }
+                const int64_t kn = k + kUnroll;
+                if (kn < k1) fetch_batch(kn, k_last);
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     if (u < rem && kept[u]) {
@@ -386,10 +401,10 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                         for (int v = 0; v < VPL; ++v)
 #pragma unroll
                             for (int e = 0; e < VEC; ++e)
-                                acc[v][e] = __fadd_rn(acc[v][e], __fmul_rn(a[u], bv[u][v][e]));
+                                acc[v][e] = __fadd_rn(acc[v][e], __fmul_rn(a_now[u], bv[u][v][e]));
                     }
                 }
-                k += kUnroll;
+                k = kn;
             }
         }
     }
