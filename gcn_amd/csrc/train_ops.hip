@@ -1,0 +1,107 @@
+// The elementwise tail of a training step as two kernels: masked softmax cross-entropy with its
+// gradient (gcn/metrics.py:85-101, gcn/models.py:92-99) and TensorFlow's Adam update
+// (gcn/models.py:35-38, 86).  On the citation graphs these replace ~35 launches of a few
+// microseconds each; on a 2^24-node graph they read the logits once instead of a dozen times.
+#include <algorithm>
+
+#include "common.h"
+
+namespace gcn {
+
+constexpr int kBlock = 256;
+
+// One thread per node.  row_stats[i] = (CE_i * w_i, correct_i * w_i) with w_i = mask_i / mean(mask);
+// dlogits[i][c] = d(mean_i CE_i w_i) / d logits[i][c] = (softmax_ic * sum_c labels_ic - labels_ic) * w_i / n.
+// An all-zero label row (CiteSeer's padded nodes) has CE 0 and argmax 0, as TensorFlow gives.
+__global__ void softmax_xent_kernel(int64_t n, int c, const float* __restrict__ logits, int64_t ldx,
+                                    const int32_t* __restrict__ labels, int64_t ldl,
+                                    const int32_t* __restrict__ mask, float mask_mean,
+                                    float* __restrict__ row_stats, float* __restrict__ dlogits, int64_t ldd) {
+    const float inv_n = 1.0f / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* x = logits + i * ldx;
+        const int32_t* lab = labels + i * ldl;
+        float mx = x[0];
+        int arg_x = 0, arg_l = 0;
+        int32_t best_l = lab[0];
+        float lab_sum = (float)lab[0];
+        for (int j = 1; j < c; ++j) {
+            const float v = x[j];
+            if (v > mx) {
+                mx = v;
+                arg_x = j;
+            }
+            const int32_t l = lab[j];
+            if (l > best_l) {
+                best_l = l;
+                arg_l = j;
+            }
+            lab_sum += (float)l;
+        }
+        float s = 0.0f;
+        for (int j = 0; j < c; ++j) s += expf(x[j] - mx);
+        const float lse = mx + logf(s);
+        float ce = 0.0f;
+        for (int j = 0; j < c; ++j) ce += (float)lab[j] * (lse - x[j]);
+        const float w = (float)mask[i] / mask_mean;
+        row_stats[2 * i] = ce * w;
+        row_stats[2 * i + 1] = (arg_x == arg_l) ? w : 0.0f;
+        if (dlogits) {
+            const float scale = w * inv_n;
+            float* d = dlogits + i * ldd;
+            for (int j = 0; j < c; ++j) d[j] = (expf(x[j] - lse) * lab_sum - (float)lab[j]) * scale;
+        }
+    }
+}
+
+// g' = g + wd * p;  m += (1 - b1)(g' - m);  v += (1 - b2)(g'^2 - v);  p -= lr_t * m / (sqrt(v) + eps).
+// lr_t comes from device memory when lr_dev is set (a launch recorded in a HIP graph).
+__global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float lr_t, const float* __restrict__ lr_dev, float one_minus_b1,
+                            float one_minus_b2, float eps, float wd) {
+    if (lr_dev) lr_t = *lr_dev;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float w = p[i];
+        const float gi = __fadd_rn(g[i], __fmul_rn(wd, w));
+        const float mi = __fadd_rn(m[i], __fmul_rn(one_minus_b1, __fsub_rn(gi, m[i])));
+        const float vi = __fadd_rn(v[i], __fmul_rn(one_minus_b2, __fsub_rn(__fmul_rn(gi, gi), v[i])));
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = __fsub_rn(w, __fdiv_rn(__fmul_rn(lr_t, mi), __fadd_rn(__fsqrt_rn(vi), eps)));
+    }
+}
+
+}  // namespace gcn
+
+using namespace gcn;
+
+extern "C" {
+
+int gcn_softmax_xent_f32(int64_t n, int64_t c, const float* logits, int64_t ldx, const int32_t* labels, int64_t ldl,
+                         const int32_t* mask, float mask_mean, float* row_stats, float* dlogits, int64_t ldd,
+                         void* stream) {
+    if (n < 0 || c < 1 || c > INT32_MAX || ldx < c || ldl < c || (dlogits && ldd < c))
+        return fail(GCN_ERR_BAD_ARG, "bad shape: n=%lld c=%lld", (long long)n, (long long)c);
+    if (!(mask_mean > 0.0f)) return fail(GCN_ERR_BAD_ARG, "mask_mean must be positive (an empty mask has no loss)");
+    if (n == 0) return GCN_OK;
+    if (!logits || !labels || !mask || !row_stats) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    const int64_t blocks = std::min<int64_t>(ceil_div(n, kBlock), 1 << 16);
+    softmax_xent_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n, (int)c, logits, ldx, labels, ldl, mask,
+                                                                             mask_mean, row_stats, dlogits, ldd);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_adam_f32(int64_t n, float* param, const float* grad, float* m, float* v, float lr_t, const float* lr_t_device,
+                 float beta1, float beta2, float epsilon, float weight_decay, void* stream) {
+    if (n < 0) return fail(GCN_ERR_BAD_ARG, "negative size");
+    if (n == 0) return GCN_OK;
+    if (!param || !grad || !m || !v) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    const int64_t blocks = std::min<int64_t>(ceil_div(n, kBlock), 1 << 16);
+    adam_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n, param, grad, m, v, lr_t, lr_t_device,
+                                                                     1.0f - beta1, 1.0f - beta2, epsilon, weight_decay);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+}  // extern "C"

@@ -12,7 +12,7 @@ import torch
 
 from . import graph, sparse
 from .layers import GraphConvolution, relu
-from .metrics import masked_accuracy, masked_softmax_cross_entropy
+from .metrics import masked_accuracy
 
 
 class TfAdam(object):
@@ -41,14 +41,12 @@ class TfAdam(object):
             p.addcdiv_(m, v.sqrt().add_(self.eps), value=-lr_t)
 
     @torch.no_grad()
-    def step_recorded(self, grads, lr_t):
-        """The same update with the step size read from a device scalar, so that the launches can be
-        recorded once (HIP graph) and replayed: the caller stores step_size(t) in ``lr_t`` before each
-        replay and keeps ``t`` itself."""
+    def step_fused(self, grads, lr_t, weight_decay=0.0):
+        """One kernel per variable (gcn_adam_f32); ``grads`` exclude the weight-decay term, which the
+        kernel adds as weight_decay * var.  ``lr_t`` is a float, or a 0-d device tensor holding
+        step_size(t) when the launches are recorded in a HIP graph (the caller keeps ``t``)."""
         for p, g, m, v in zip(self.params, grads, self.m, self.v):
-            m.add_(g - m, alpha=1.0 - self.b1)
-            v.add_(g * g - v, alpha=1.0 - self.b2)
-            p.sub_(lr_t * (m / v.sqrt().add_(self.eps)))
+            sparse.adam_step(p, g, m, v, lr_t, self.b1, self.b2, self.eps, weight_decay)
 
 
 class GCN_MLP(object):
@@ -167,13 +165,18 @@ class GCN_MLP(object):
             self.activations.append(hidden)
         return hidden
 
-    def _loss(self, outputs, labels, mask):
-        """gcn/models.py:92-99: weight decay on EVERY variable of EVERY layer + masked cross-entropy."""
-        loss = 0
-        for layer in self.layers:
-            for var in layer.vars.values():
-                loss = loss + self.model_config['weight_decay'] * (var * var).sum() / 2
-        return loss + masked_softmax_cross_entropy(outputs, labels, mask)
+    def _mask_mean(self, mask):
+        """mean(mask) as a host float, computed once per fed mask."""
+        hit = self._device_cache.get(('mask_mean', id(mask)))
+        if hit is None or hit[0] is not mask:
+            hit = (mask, float(mask.to(torch.float32).mean().item()))
+            self._device_cache[('mask_mean', id(mask))] = hit
+        return hit[1]
+
+    def _weight_decay_term(self):
+        """gcn/models.py:94-96: weight_decay * l2_loss(var) summed over every variable of every layer."""
+        wd = self.model_config['weight_decay']
+        return sum(wd * (var * var).sum() / 2 for layer in self.layers for var in layer.vars.values())
 
     # ------------------------------------------------------------------ #
     # the train step as one HIP graph
@@ -193,6 +196,7 @@ class GCN_MLP(object):
         the model state that step changes is put back before the capture."""
         labels = self.placeholders['labels'].value
         mask = self.placeholders['labels_mask'].value
+        mask_mean = self._mask_mean(mask)
         params = self._trainable()
         snapshot = [p.detach().clone() for p in params + self.optimizer.m + self.optimizer.v]
         dev = params[0].device
@@ -205,14 +209,17 @@ class GCN_MLP(object):
             with sparse.stream_offset(rec['offset']):
                 with torch.enable_grad():
                     outputs = self._forward()
-                    loss = self._loss(outputs, labels, mask)
-                    grads = torch.autograd.grad(loss, params)
-                self.optimizer.step_recorded(grads, rec['lr_t'])
+                    stats, dlogits = sparse.softmax_xent(outputs.detach(), labels, mask, mask_mean)
+                    grads = torch.autograd.grad(outputs, params, grad_outputs=dlogits)
                 with torch.no_grad():
-                    rec['loss'] = loss.detach()
                     rec['outputs'] = outputs.detach()
-                    rec['accuracy'] = masked_accuracy(outputs, labels, mask)
-                    rec['prediction'] = torch.softmax(outputs.detach(), dim=1)
+                    if 'loss' in keys or 'accuracy' in keys:
+                        means = stats.mean(dim=0)
+                        rec['accuracy'] = means[1]
+                        rec['loss'] = means[0] + self._weight_decay_term() if 'loss' in keys else means[0]
+                    if 'prediction' in keys:
+                        rec['prediction'] = torch.softmax(outputs.detach(), dim=1)
+                self.optimizer.step_fused(grads, rec['lr_t'], self.model_config['weight_decay'])
 
         import warnings
         side = torch.cuda.Stream(device=dev)
@@ -264,14 +271,23 @@ class GCN_MLP(object):
         mask = self.placeholders['labels_mask'].value
         train = 'opt_op' in keys
         out = {}
+        need_stats = train or 'loss' in keys or 'accuracy' in keys
         with torch.set_grad_enabled(train):
             outputs = self._forward()
-            need_loss = train or 'loss' in keys
-            loss = self._loss(outputs, labels, mask) if need_loss else None
+            stats = loss = None
+            if need_stats:      # loss rows, accuracy rows and d loss / d logits in one pass over the logits
+                stats, dlogits = sparse.softmax_xent(outputs.detach(), labels, mask, self._mask_mean(mask),
+                                                     want_grad=train)
+                stats = stats.mean(dim=0)
+            if 'loss' in keys:
+                with torch.no_grad():
+                    loss = stats[0] + self._weight_decay_term()        # with the weights of this run's forward
             if train:
                 params = self._trainable()
-                grads = torch.autograd.grad(loss, params)
-                self.optimizer.step(grads)
+                grads = torch.autograd.grad(outputs, params, grad_outputs=dlogits)
+                self.optimizer.t += 1
+                self.optimizer.step_fused(grads, self.optimizer.step_size(self.optimizer.t),
+                                          self.model_config['weight_decay'])
                 self.global_step += 1
                 out['opt_op'] = None
         with torch.no_grad():
@@ -282,7 +298,7 @@ class GCN_MLP(object):
             if 'loss' in keys:
                 out['loss'] = np.float32(loss.item())
             if 'accuracy' in keys:
-                out['accuracy'] = np.float32(masked_accuracy(outputs, labels, mask).item())     # models.py:106-108
+                out['accuracy'] = np.float32(stats[1].item())                                   # models.py:106-108
             if 'accuracy_of_class' in keys:
                 m = mask.to(torch.float32)
                 out['accuracy_of_class'] = [

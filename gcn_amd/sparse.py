@@ -436,3 +436,37 @@ def gemm_tn(a, g, out=None):
     _lib.call('gcn_gemm_tn_f32', m, n, k, _p(a), _ld(a), _p(g), _ld(g), _p(out), _ld(out), _p(ws), nbytes.value,
               _stream())
     return out
+
+
+def softmax_xent(logits, labels, mask, mask_mean, want_grad=True):
+    """Per-row (masked cross-entropy, masked correctness) [n x 2] and, with ``want_grad``, the gradient
+    of the mean loss w.r.t. the logits.  ``labels`` int32 one-hot [n x c], ``mask`` int32 [n]."""
+    _require_cuda(logits, labels, mask)
+    logits = _rowmajor(logits)
+    if labels.dtype != torch.int32 or mask.dtype != torch.int32:
+        raise ValueError('labels and mask must be int32')
+    labels = labels.contiguous()
+    mask = mask.contiguous()
+    n, c = logits.shape
+    if tuple(labels.shape) != (n, c) or mask.numel() != n:
+        raise ValueError('labels / mask do not match the logits')
+    stats = torch.empty((n, 2), dtype=torch.float32, device=logits.device)
+    grad = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_grad else None
+    _lib.call('gcn_softmax_xent_f32', n, c, _p(logits), _ld(logits), _p(labels), c, _p(mask), float(mask_mean),
+              _p(stats), _p(grad), c, _stream())
+    return stats, grad
+
+
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, epsilon=1e-8, weight_decay=0.0):
+    """In-place Adam update of one contiguous float32 variable; ``lr_t`` is a float or a 0-d device tensor."""
+    _require_cuda(param, grad, m, v)
+    if not (param.is_contiguous() and m.is_contiguous() and v.is_contiguous()) or param.dtype != torch.float32:
+        raise ValueError('adam_step wants contiguous float32 state')
+    grad = grad.contiguous()
+    if grad.numel() != param.numel():
+        raise ValueError('gradient does not match the variable')
+    on_device = isinstance(lr_t, torch.Tensor)
+    _lib.call('gcn_adam_f32', param.numel(), _p(param), _p(grad), _p(m), _p(v), 0.0 if on_device else float(lr_t),
+              _p(lr_t) if on_device else ctypes.c_void_p(0), float(beta1), float(beta2), float(epsilon),
+              float(weight_decay), _stream())
+    return param

@@ -210,6 +210,28 @@ int gcn_gemm_tn_workspace_bytes(int64_t m, int64_t n, int64_t k, size_t* bytes);
 int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* g, int64_t ldg,
                     float* c, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Loss and optimiser of the training step.                                   *
+ * ------------------------------------------------------------------------- */
+
+/* masked_softmax_cross_entropy and masked_accuracy (gcn/metrics.py:85-101) in one pass over the
+ * logits, plus the gradient of the loss w.r.t. the logits that optimizer.minimize (gcn/models.py:86)
+ * would derive.  labels: int32 one-hot [n x c] (all-zero rows allowed); mask: int32 [n];
+ * mask_mean = mean(mask) > 0.  row_stats [n x 2]: (CE_i * w_i, correct_i * w_i) with
+ * w_i = mask_i / mask_mean -- the caller's mean over n of column 0 is the data term of the loss, of
+ * column 1 the accuracy.  dlogits (may be NULL) [n x c] = (softmax_i * sum(labels_i) - labels_i) * w_i / n. */
+int gcn_softmax_xent_f32(int64_t n, int64_t c, const float* logits, int64_t ldx, const int32_t* labels, int64_t ldl,
+                         const int32_t* mask, float mask_mean, float* row_stats, float* dlogits, int64_t ldd,
+                         void* stream);
+
+/* One tf.train.AdamOptimizer step on one variable (gcn/models.py:35-38) with the weight-decay term of
+ * the loss (gcn/models.py:94-96) folded into the gradient: g' = g + weight_decay * p;
+ * m += (1 - beta1)(g' - m); v += (1 - beta2)(g'^2 - v); p -= lr_t * m / (sqrt(v) + epsilon), where
+ * lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) is computed by the caller.  lr_t_device (may be NULL):
+ * read lr_t from device memory instead (a launch recorded in a HIP graph). */
+int gcn_adam_f32(int64_t n, float* param, const float* grad, float* m, float* v, float lr_t, const float* lr_t_device,
+                 float beta1, float beta2, float epsilon, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

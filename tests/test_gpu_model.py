@@ -95,14 +95,18 @@ def test_gradients_and_adam_steps(name, oracle):
     labels, mask = fx['y_train'], fx['train_mask']
     # raw gradients, dropout off
     model._bind(feed)
+    from gcn_amd import sparse
     with torch.enable_grad():
         out = model._forward()
-        loss = model._loss(out, ph['labels'].value, ph['labels_mask'].value)
-        grads = torch.autograd.grad(loss, model._trainable())
+        dev_mask = ph['labels_mask'].value
+        stats, dlogits = sparse.softmax_xent(out.detach(), ph['labels'].value, dev_mask, model._mask_mean(dev_mask))
+        grads = torch.autograd.grad(out, model._trainable(), grad_outputs=dlogits)
     logits = ref.forward()
     ref_grads = ref.backward(logits, labels, mask)
-    for g, rg in zip(grads, ref_grads):
-        assert _close(g.cpu().numpy(), rg, 2e-5)
+    for g, w, rg in zip(grads, model._trainable(), ref_grads):     # the optimiser kernel adds weight_decay * w
+        assert _close((g + 5e-4 * w.detach()).cpu().numpy(), rg, 2e-5)
+    assert abs(float(stats[:, 0].mean()) - float(ref.masked_softmax_cross_entropy(logits, labels, mask))) <= 1e-6
+    assert abs(float(stats[:, 1].mean()) - float(ref.masked_accuracy(logits, labels, mask))) <= 1e-6
     # three optimiser steps (TensorFlow's Adam form), dropout off
     sess = tf.Session()
     adam = oracle.TfAdam(ref.w, 0.02)
