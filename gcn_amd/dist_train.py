@@ -73,6 +73,7 @@ class ShardedGCN(object):
             w = (torch.rand((fan_in, fan_out), generator=g, device=dev, dtype=torch.float32) * 2 - 1) * r
             self.weights.append(w.requires_grad_(True))
         self.optimizer = TfAdam(self.weights, learning_rate)
+        self._mask_cache = {}
         self.step_count = 0
 
     def _all_reduce(self, t):
@@ -92,29 +93,37 @@ class ShardedGCN(object):
             h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks)
         return h
 
-    def loss_terms(self, logits, labels_local, mask_local):
-        """Local part of gcn/metrics.py:85-92 with the mask normalised globally, and the global mask mean."""
-        n_global = self.shard.n_rows_global
-        mask = mask_local.to(torch.float32)
-        mask_sum = self._all_reduce(mask.sum().detach().clone())
-        mask_mean = mask_sum / n_global
-        ce = -(labels_local.to(torch.float32) * torch.log_softmax(logits, dim=1)).sum(dim=1)
-        return (ce * mask).sum() / (mask_mean * n_global)
+    def _local_mask_mean(self, mask_local):
+        """The value that makes the loss kernel weigh a local row by mask_i / (global mask count): it
+        divides by mask_mean and by the local row count, so pass mean_global * n_global / n_local.
+        The global count is reduced once per mask tensor."""
+        hit = self._mask_cache.get(id(mask_local))
+        if hit is None or hit[0] is not mask_local:
+            count = self._all_reduce(mask_local.to(torch.float32).sum().reshape(1))
+            hit = (mask_local, float(count.item()) / mask_local.numel())
+            self._mask_cache[id(mask_local)] = hit
+        return hit[1]
 
     def train_step(self, x_local, labels_local, mask_local):
-        """One optimiser step; returns the global loss (data term + weight decay) as a 0-d tensor."""
+        """One optimiser step; returns the global loss (data term + weight decay) as a 0-d tensor.
+        Loss, accuracy rows and d loss / d logits come from one kernel over the local logits
+        (gcn/metrics.py:85-92 with the mask normalised globally); the weight gradients and the loss are
+        summed over the ranks in one all-reduce; Adam and the weight-decay term run in one kernel per
+        variable."""
         self.step_count += 1
+        mask_mean = self._local_mask_mean(mask_local)
         with torch.enable_grad():
             logits = self.forward(x_local, train=True)
-            local = self.loss_terms(logits, labels_local, mask_local)
-            grads = torch.autograd.grad(local, self.weights)
-        flat = torch.cat([g.reshape(-1) for g in grads] + [local.detach().reshape(1)])
+            stats, dlogits = sparse.softmax_xent(logits.detach(), labels_local, mask_local, mask_mean)
+            grads = torch.autograd.grad(logits, self.weights, grad_outputs=dlogits)
+        flat = torch.cat([g.reshape(-1) for g in grads] + [stats[:, 0].mean().reshape(1)])
         self._all_reduce(flat)
+        with torch.no_grad():
+            reg = sum(self.wd * (w * w).sum() / 2 for w in self.weights)       # with the weights of this forward
         pos, summed = 0, []
         for w in self.weights:
-            summed.append(flat[pos:pos + w.numel()].view_as(w) + self.wd * w.detach())   # + d/dw of wd * |w|^2 / 2
+            summed.append(flat[pos:pos + w.numel()].view_as(w))
             pos += w.numel()
-        self.optimizer.step(summed)
-        with torch.no_grad():
-            reg = sum(self.wd * (w * w).sum() / 2 for w in self.weights)
+        self.optimizer.t += 1
+        self.optimizer.step_fused(summed, self.optimizer.step_size(self.optimizer.t), self.wd)
         return flat[pos] + reg

@@ -151,3 +151,45 @@ def test_sharded_training_step_matches_single_gpu(tmp_path):
     w1, w2 = np.load(tmp_path / 'w0_w1.npy'), np.load(tmp_path / 'w0_w2.npy')
     d = np.abs(w1 - w2)
     assert (d <= 1e-5 * np.abs(w1).max()).mean() >= 0.999 and d.max() <= 1e-3 * np.abs(w1).max()
+
+
+def test_sharded_step_against_a_dense_float64_model():
+    """The sharded model on one rank, dropout off, against the same 2-layer GCN written with dense
+    float64 torch operations and autograd: loss trajectory over 4 Adam steps."""
+    from gcn_amd import dist as gdist, sparse
+    from gcn_amd.dist_train import ShardedGCN
+    scale, f_in, hidden, classes = 10, 24, 16, 5
+    n = 1 << scale
+    indptr, indices = sparse.rmat_csr(scale, 8, seed=3, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, 1)
+    x = sparse.synthetic_dense(n, f_in, seed=7)
+    gen = torch.Generator().manual_seed(5)
+    cls = torch.randint(0, classes, (n,), generator=gen)
+    labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32).cuda()
+    mask = (torch.rand(n, generator=gen) < 0.2).to(torch.int32).cuda()
+    model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.0, seed=9)
+    # dense float64 twin
+    rows = torch.repeat_interleave(torch.arange(n, device='cuda'), indptr[1:] - indptr[:-1])
+    a = torch.zeros((n, n), dtype=torch.float64, device='cuda')
+    a[rows, indices.long()] = vals.double()
+    w = [p.detach().double().clone().requires_grad_(True) for p in model.weights]
+    m = [torch.zeros_like(p) for p in w]
+    v = [torch.zeros_like(p) for p in w]
+    lab64, mask64 = labels.double(), mask.double()
+    for t in range(1, 5):
+        h = torch.relu(a @ (x.double() @ w[0]))
+        logits = a @ (h @ w[1])
+        ce = -(lab64 * torch.log_softmax(logits, dim=1)).sum(dim=1)
+        ref_loss = (ce * mask64 / mask64.mean()).mean() + sum(5e-4 * (p * p).sum() / 2 for p in w)
+        grads = torch.autograd.grad(ref_loss, w)
+        loss = float(model.train_step(x, labels, mask))
+        ref_value = float(ref_loss.detach())
+        assert abs(loss - ref_value) <= 1e-4 * abs(ref_value), (t, loss, ref_value)
+        lr_t = 0.02 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        with torch.no_grad():
+            for p, g, mm, vv in zip(w, grads, m, v):
+                mm += 0.1 * (g - mm)
+                vv += 0.001 * (g * g - vv)
+                p -= lr_t * mm / (vv.sqrt() + 1e-8)
