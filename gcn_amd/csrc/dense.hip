@@ -69,7 +69,9 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
     constexpr int kBPer = (kBUnits + kBlock - 1) / kBlock;  // per thread
     constexpr bool kBAll = kBUnits % kBlock == 0;           // every thread has kBPer units
     __shared__ __attribute__((aligned(16))) float as[kBM * kAPitch];
-    __shared__ __attribute__((aligned(16))) float bs[kBK * kBPitch];
+    // B tile: k-major [kBK][BN + 4] when B is stored [k x n]; column-major [BN][kBK + 4] (the layout of
+    // the A tile) when B is stored [n x k], so that it too is written and read 128 bits at a time
+    __shared__ __attribute__((aligned(16))) float bs[TRANS_B ? BN * kAPitch : kBK * kBPitch];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -163,10 +165,7 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
             if (!kBAll && u >= kBUnits) continue;
             if (TRANS_B) {
                 const int col = u / kKQ, kq = (u % kKQ) * 4;
-                bs[(kq + 0) * kBPitch + col] = rb[p].x;
-                bs[(kq + 1) * kBPitch + col] = rb[p].y;
-                bs[(kq + 2) * kBPitch + col] = rb[p].z;
-                bs[(kq + 3) * kBPitch + col] = rb[p].w;
+                *reinterpret_cast<float4*>(bs + col * kAPitch + kq) = rb[p];
             } else {
                 *reinterpret_cast<float4*>(bs + (u / (BN / 4)) * kBPitch + (u % (BN / 4)) * 4) = rb[p];
             }
@@ -182,8 +181,16 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
             av[i] = *reinterpret_cast<const float4*>(as + ((wm * MT + i) * 32 + l31) * kAPitch + kh + kq);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
+            if (TRANS_B) {
+                const float4 t = *reinterpret_cast<const float4*>(bs + ((wn * NT + j) * 32 + l31) * kAPitch + kh + kq);
+                bv[j][0] = t.x;
+                bv[j][1] = t.y;
+                bv[j][2] = t.z;
+                bv[j][3] = t.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[j][e] = bs[(kh + kq + e) * kBPitch + (wn * NT + j) * 32 + l31];
+                for (int e = 0; e < 4; ++e) bv[j][e] = bs[(kh + kq + e) * kBPitch + (wn * NT + j) * 32 + l31];
+            }
     };
     auto mfma_group = [&](const float4 (&av)[MT], const float (&bv)[NT][4]) {
 #pragma unroll
