@@ -28,6 +28,36 @@ __global__ void dropout_kernel(int64_t n_rows, int64_t f, const float* __restric
     }
 }
 
+// The same on contiguous matrices (row stride = width, 16-byte aligned, element count a multiple of 4):
+// 128-bit accesses, no division per element, and no hash at all when keep_prob is 1 (the pure
+// ReLU-gate pass of the backward).
+template <bool RNG>
+__global__ void dropout_vec_kernel(int64_t n_vec, const float4* __restrict__ x, const float4* __restrict__ gate,
+                                   float4* __restrict__ y, float keep_prob, uint64_t key, uint64_t index_offset,
+                                   const uint64_t* __restrict__ stream_offset, uint64_t seed, uint64_t stream_id) {
+    if (RNG && stream_offset) key = stream_key(seed, stream_id + *stream_offset);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (RNG) {
+            const uint64_t id = index_offset + 4 * (uint64_t)i;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = __fdiv_rn(o[e], keep_prob);
+                o[e] = keep_entry(key, id + e, keep_prob) ? o[e] : 0.0f;
+            }
+        }
+        if (gate) {
+            const float4 g = gate[i];
+            if (!(g.x > 0.0f)) o[0] = 0.0f;
+            if (!(g.y > 0.0f)) o[1] = 0.0f;
+            if (!(g.z > 0.0f)) o[2] = 0.0f;
+            if (!(g.w > 0.0f)) o[3] = 0.0f;
+        }
+        y[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C[m x n] = A[m x k] . op(B) with v_mfma_f32_32x32x2_f32 (exact float32 products and sums).
 // Block tile 128 x BN (BN = 32, 64, 128), 4 waves, K staged 32 deep through one LDS buffer; 35 KB of
@@ -497,6 +527,22 @@ int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, cons
     const int64_t total = n_rows * f;
     if (total == 0) return GCN_OK;
     if (!x || !y) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    const bool contiguous = ldx == f && ldy == f && (!gate || ldg == f) && total % 4 == 0 &&
+                            (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gate) & 15) == 0;
+    if (contiguous) {
+        const int64_t n_vec = total / 4;
+        int64_t vblocks = ceil_div(n_vec, kBlock);
+        if (vblocks > 256 * 32) vblocks = 256 * 32;
+        if (keep_prob < 1.0f)
+            dropout_vec_kernel<true><<<(unsigned)vblocks, kBlock, 0, (hipStream_t)stream>>>(
+                n_vec, (const float4*)x, (const float4*)gate, (float4*)y, keep_prob, stream_key(seed, stream_id),
+                index_offset, stream_offset, seed, stream_id);
+        else
+            dropout_vec_kernel<false><<<(unsigned)vblocks, kBlock, 0, (hipStream_t)stream>>>(
+                n_vec, (const float4*)x, (const float4*)gate, (float4*)y, keep_prob, 0, index_offset, nullptr, 0, 0);
+        GCN_LAUNCH_CHECK();
+        return GCN_OK;
+    }
     int64_t blocks = ceil_div(total, kBlock);
     if (blocks > 256 * 32) blocks = 256 * 32;
     dropout_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_rows, f, x, ldx, gate, ldg, y, ldy,

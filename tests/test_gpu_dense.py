@@ -13,17 +13,23 @@ def _t(a):
     return torch.as_tensor(np.ascontiguousarray(a)).cuda()
 
 
+@pytest.mark.parametrize('shape', [(2708, 16), (3327, 7), (1, 1), (1001, 3)])      # 128-bit path and element path
 @pytest.mark.parametrize('keep_prob', [0.5, 0.8, 1.0])
-def test_dense_dropout_bit_exact(oracle, keep_prob):
+def test_dense_dropout_bit_exact(oracle, keep_prob, shape):
     from gcn_amd import sparse
-    x = oracle.synthetic_dense(2708, 16, seed=31)
+    x = oracle.synthetic_dense(shape[0], shape[1], seed=31)
     ref, keep = oracle.dense_dropout(x, keep_prob, oracle.stream_key(99, 3))
     out = sparse.dropout(_t(x), keep_prob, 99, 3).cpu().numpy()
     assert np.array_equal(out, ref)
     # with a gate: the ReLU-backward form
-    gate = oracle.synthetic_dense(2708, 16, seed=32)
+    gate = oracle.synthetic_dense(shape[0], shape[1], seed=32)
     out_g = sparse.dropout(_t(x), keep_prob, 99, 3, gate=_t(gate)).cpu().numpy()
     assert np.array_equal(out_g, np.where(gate > 0, ref, np.float32(0)))
+    # a row shard draws its slice of the unsplit matrix's mask, on either path
+    half = shape[0] // 2
+    if half:
+        part = sparse.dropout(_t(x[half:]), keep_prob, 99, 3, index_offset=half * shape[1]).cpu().numpy()
+        assert np.array_equal(part, ref[half:])
 
 
 @pytest.mark.parametrize('m,n,k', [(2708, 7, 16), (3327, 6, 16), (19717, 3, 16), (1000, 16, 1433), (513, 130, 257),
