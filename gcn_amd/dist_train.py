@@ -25,33 +25,42 @@ def _product(plan, b_local, relu, chunks):
 
 class _HaloSpmmFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, b_local, fuse_relu, chunks):
+    def forward(ctx, plan, b_local, fuse_relu, chunks, gate_here):
+        """``gate_here`` False: the ReLU's backward gate is applied by the dropout that consumes this
+        output (one pass over the activations instead of two)."""
         out = _product(plan, b_local, fuse_relu, chunks)
-        ctx.plan, ctx.fuse_relu, ctx.chunks = plan, fuse_relu, chunks
-        if fuse_relu:
+        ctx.plan, ctx.gate, ctx.chunks = plan, fuse_relu and gate_here, chunks
+        if ctx.gate:
             ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        if ctx.fuse_relu:
+        if ctx.gate:
             out, = ctx.saved_tensors
             grad = sparse.dropout(grad, 1.0, 0, 0, gate=out)
         plan = ctx.plan
         # symmetric support: rows of A^T are rows of A
-        return None, _product(plan, grad.contiguous(), False, ctx.chunks), None, None
+        return None, _product(plan, grad.contiguous(), False, ctx.chunks), None, None, None
 
 
 class _ShardDropoutFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, keep_prob, seed, stream_id, index_offset):
+    def forward(ctx, x, keep_prob, seed, stream_id, index_offset, relu_input):
+        """``relu_input``: x is the output of a ReLU whose backward gate (x > 0) is folded into this
+        function's backward pass."""
         ctx.args = (keep_prob, seed, stream_id, index_offset)
+        ctx.relu_input = relu_input
+        if relu_input:
+            ctx.save_for_backward(x)
         return sparse.dropout(x, keep_prob, seed, stream_id, index_offset=index_offset)
 
     @staticmethod
     def backward(ctx, grad):
         keep_prob, seed, stream_id, index_offset = ctx.args
-        return sparse.dropout(grad, keep_prob, seed, stream_id, index_offset=index_offset), None, None, None, None
+        gate = ctx.saved_tensors[0] if ctx.relu_input else None
+        return (sparse.dropout(grad, keep_prob, seed, stream_id, gate=gate, index_offset=index_offset),
+                None, None, None, None, None)
 
 
 class ShardedGCN(object):
@@ -88,9 +97,10 @@ class ShardedGCN(object):
         for li, w in enumerate(self.weights):
             if keep < 1.0:
                 offset = self.shard.row_begin * h.shape[1]
-                h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64 + li, offset)
+                h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64 + li, offset, li > 0)
             p = _GemmFn.apply(h, w)
-            h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks)
+            # the next layer's dropout (if any) applies this layer's ReLU gate in its backward
+            h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not (keep < 1.0))
         return h
 
     def _local_mask_mean(self, mask_local):
