@@ -61,6 +61,7 @@ SIGNATURES = {
     'gcn_dropout_f32': [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _f32, _u64, _u64, _vp, _u64, _vp],
     'gcn_gemm_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp],
     'gcn_gemm_tn_workspace_bytes': [_i64, _i64, _i64, ctypes.POINTER(ctypes.c_size_t)],
+    'gcn_gather_rows_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp],
     'gcn_softmax_xent_f32': [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _vp],
     'gcn_adam_f32': [_i64, _vp, _vp, _vp, _vp, _f32, _vp, _f32, _f32, _f32, _f32, _vp],
     'gcn_gemm_tn_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, ctypes.c_size_t, _vp],

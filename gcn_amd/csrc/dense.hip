@@ -58,6 +58,26 @@ __global__ void dropout_vec_kernel(int64_t n_vec, const float4* __restrict__ x, 
     }
 }
 
+// dst[i, :] = src[rows[i], :] for a column range of a row-major matrix: the send buffer of the
+// multi-GPU exchange (the rows of the local block that other ranks reference).  One thread per
+// float4 (or per float when the layout does not allow 128-bit accesses).
+template <int VEC>
+__global__ void gather_rows_kernel(int64_t n_out, int64_t f, const float* __restrict__ src, int64_t lds_,
+                                   const int64_t* __restrict__ rows, float* __restrict__ dst, int64_t ldd) {
+    const int64_t per_row = (f + VEC - 1) / VEC;
+    const int64_t total = n_out * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per_row, c = (i - r * per_row) * VEC;
+        const float* s = src + rows[r] * lds_ + c;
+        float* d = dst + r * ldd + c;
+        if (VEC == 4) {
+            *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(s);
+        } else {
+            d[0] = s[0];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C[m x n] = A[m x k] . op(B) with v_mfma_f32_32x32x2_f32 (exact float32 products and sums).
 // Block tile 128 x BN (BN = 32, 64, 128), 4 waves, K staged 32 deep through one LDS buffer; 35 KB of
@@ -548,6 +568,22 @@ int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, cons
     dropout_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_rows, f, x, ldx, gate, ldg, y, ldy,
                                                                         keep_prob, stream_key(seed, stream_id), index_offset,
                                                                         stream_offset, seed, stream_id);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_gather_rows_f32(int64_t n_out, int64_t f, int64_t n_src_rows, const float* src, int64_t ld_src,
+                        const int64_t* rows, float* dst, int64_t ld_dst, void* stream) {
+    if (n_out < 0 || f < 0 || n_src_rows < 0 || ld_src < f || ld_dst < f) return fail(GCN_ERR_BAD_ARG, "bad shape");
+    if (n_out == 0 || f == 0) return GCN_OK;
+    if (!src || !rows || !dst) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    const bool vec = (f % 4 == 0) && (ld_src % 4 == 0) && (ld_dst % 4 == 0) && ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
+    const int64_t work = n_out * (vec ? f / 4 : f);
+    const int64_t blocks = std::min<int64_t>(ceil_div(work, kBlock), 1 << 16);
+    if (vec)
+        gather_rows_kernel<4><<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_out, f, src, ld_src, rows, dst, ld_dst);
+    else
+        gather_rows_kernel<1><<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_out, f, src, ld_src, rows, dst, ld_dst);
     GCN_LAUNCH_CHECK();
     return GCN_OK;
 }

@@ -159,7 +159,10 @@ class HaloPlan(object):
                     torch.empty((self.n_needed, f), dtype=torch.float32, device=dev))
             self._buffers[(f, slot)] = bufs
         send_buf, b_halo = bufs
-        torch.index_select(b_local, 0, self.send_rows, out=send_buf)
+        if b_local.is_cuda:
+            sparse.gather_rows(b_local, self.send_rows, send_buf)      # column slices are read in place
+        else:
+            torch.index_select(b_local, 0, self.send_rows, out=send_buf)
         work = _Done
         if self._collective:
             if async_op and not _through_host(b_halo, self.group):

@@ -470,3 +470,16 @@ def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, epsilon=1e-8, wei
               _p(lr_t) if on_device else ctypes.c_void_p(0), float(beta1), float(beta2), float(epsilon),
               float(weight_decay), _stream())
     return param
+
+
+def gather_rows(src, rows, out):
+    """``out[i] = src[rows[i]]`` for a row-major float32 matrix (or a column slice of one) and int64 row ids."""
+    _require_cuda(src, rows, out)
+    if src.dim() != 2 or src.dtype != torch.float32 or (src.shape[1] > 1 and src.stride(1) != 1):
+        raise ValueError('gather_rows wants a row-major float32 matrix')
+    if rows.dtype != torch.int64 or not rows.is_contiguous():
+        raise ValueError('row ids must be contiguous int64')
+    _check_out(out, rows.numel(), src.shape[1])
+    _lib.call('gcn_gather_rows_f32', rows.numel(), src.shape[1], src.shape[0], _p(src), _ld(src), _p(rows), _p(out),
+              _ld(out), _stream())
+    return out

@@ -210,6 +210,13 @@ int gcn_gemm_tn_workspace_bytes(int64_t m, int64_t n, int64_t k, size_t* bytes);
 int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* g, int64_t ldg,
                     float* c, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream);
 
+/* dst[i, 0:f] = src[rows[i], 0:f]: packs the rows of a rank's block of a dense matrix that other ranks
+ * reference into the send buffer of the multi-GPU exchange (no counterpart in the single-process
+ * reference; the dense operand is the `pre_sup` of gcn/layers.py:198-202).  rows: int64 [n_out], every
+ * value in [0, n_src_rows) -- not checked. */
+int gcn_gather_rows_f32(int64_t n_out, int64_t f, int64_t n_src_rows, const float* src, int64_t ld_src,
+                        const int64_t* rows, float* dst, int64_t ld_dst, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Loss and optimiser of the training step.                                   *
  * ------------------------------------------------------------------------- */

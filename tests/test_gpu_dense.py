@@ -104,3 +104,20 @@ def test_weight_gradient_product_against_float64(oracle, m, n, k):
     got = c_wide.cpu().numpy()
     assert np.abs(got[:, 2:2 + n] - ref).max() <= tol
     assert np.all(got[:, :2] == 3.0) and np.all(got[:, 2 + n:] == 3.0)
+
+
+def test_gather_rows_of_a_column_range():
+    """The send-buffer pack of the exchange: rows picked from a column slice of a wider matrix, with the
+    128-bit path (aligned slice) and the element path (odd offset / width)."""
+    import torch
+    from gcn_amd import sparse
+    gen = torch.Generator().manual_seed(3)
+    src = torch.rand((5000, 72), generator=gen).cuda()
+    rows = torch.randint(0, 5000, (12345,), generator=gen).cuda()
+    for c0, c1 in ((0, 72), (8, 40), (3, 10), (64, 72)):
+        out = torch.full((rows.numel(), c1 - c0 + 4), -1.0, device='cuda')
+        sparse.gather_rows(src[:, c0:c1], rows, out[:, :c1 - c0])
+        assert torch.equal(out[:, :c1 - c0], src[rows][:, c0:c1])
+        assert bool((out[:, c1 - c0:] == -1.0).all())
+    empty = torch.empty((0, 72), device='cuda')
+    sparse.gather_rows(src, rows[:0], empty)
