@@ -278,7 +278,7 @@ def main():
             'config': {'workload': 'A_hat.B, R-MAT scale %d edge factor %d (+I, sym-normalised), F=%d'
                                    % (args.scale, args.edge_factor, f),
                        'n_nodes': n, 'nnz': nnz, 'features': f,
-                       'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B in %d column ranges, overlapped with the product' % args.chunks)) if world > 1 else 'single GPU'},
+                       'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B in %d progressive column ranges, overlapped with the product' % args.chunks)) if world > 1 else 'single GPU'},
             'pct_of_hbm_peak': 100.0 * value / (HBM_PEAK_GBPS * world),
             'gather_gbps': total_gather / (ms_per_step * 1e-3) / 1e9,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

@@ -182,20 +182,32 @@ class _Done(object):
         return True
 
 
-def column_chunks(f, chunks):
+def column_chunks(f, chunks, progressive=True):
     """Split f feature columns into at most ``chunks`` contiguous ranges whose widths are multiples
-    of 4 floats (128-bit loads stay possible in every range)."""
+    of 4 floats (128-bit loads stay possible in every range).
+
+    ``progressive``: widths in the proportions 1 : 1 : 2 : 4 : ... (32, 32, 64, 128 for f = 256,
+    chunks = 4).  The exchange of the first range is the only one a pipelined product waits for, so it
+    should be short; each later exchange hides behind the product of the range before it as long as
+    a range is at most about twice that one -- moving a column is faster than multiplying it on 2, 4
+    and 8 GPUs of the scale-24 graph."""
     if chunks <= 1 or f < 8:
         return [(0, f)]
     quads = (f + 3) // 4
     chunks = min(chunks, quads)
-    bounds, start = [], 0
-    for i in range(chunks):
-        stop = min(f, 4 * ((quads * (i + 1)) // chunks))
-        if stop > start:
-            bounds.append((start, stop))
-        start = stop
-    return bounds
+    if progressive:
+        while chunks > 1 and quads < (1 << (chunks - 1)):
+            chunks -= 1
+        units = 1 << (chunks - 1)
+        shares = [1] + [1 << max(i - 1, 0) for i in range(1, chunks)]      # 1, 1, 2, 4, ...
+        edges, acc = [0], 0
+        for share in shares:
+            acc += share
+            edges.append(min(f, 4 * ((quads * acc) // units)))
+    else:
+        edges = [0] + [min(f, 4 * ((quads * (i + 1)) // chunks)) for i in range(chunks)]
+    edges[-1] = f
+    return [(lo, hi) for lo, hi in zip(edges, edges[1:]) if hi > lo]
 
 
 class HaloSpmm(object):

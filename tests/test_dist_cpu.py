@@ -100,10 +100,13 @@ def test_column_chunks_cover_every_column_once():
     from gcn_amd import dist as gdist
     for f in (1, 6, 7, 16, 100, 256, 513):
         for chunks in (1, 2, 4, 7):
-            ranges = gdist.column_chunks(f, chunks)
-            assert ranges[0][0] == 0 and ranges[-1][1] == f and len(ranges) <= max(chunks, 1)
-            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
-            assert all(lo % 4 == 0 and hi > lo for lo, hi in ranges)
+            for progressive in (True, False):
+                ranges = gdist.column_chunks(f, chunks, progressive=progressive)
+                assert ranges[0][0] == 0 and ranges[-1][1] == f and len(ranges) <= max(chunks, 1)
+                assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+                assert all(lo % 4 == 0 and hi > lo for lo, hi in ranges)
+    assert gdist.column_chunks(256, 4) == [(0, 32), (32, 64), (64, 128), (128, 256)]
+    assert gdist.column_chunks(256, 4, progressive=False) == [(0, 64), (64, 128), (128, 192), (192, 256)]
 
 
 def test_row_block_requires_equal_blocks():
