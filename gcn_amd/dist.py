@@ -114,6 +114,12 @@ class HaloPlan(object):
         per = shard.n_cols // world
         if shard.n_cols % world != 0:
             raise ValueError('n_cols=%d is not a multiple of the world size %d' % (shard.n_cols, world))
+        self._collective = world > 1 or (dist.is_initialized() and dist.get_world_size(group) == 1)
+        if not self._collective and shard.n_cols == local.n_rows:
+            # one process, no communicator: the shard is the matrix and B is its own operand
+            self.compact, self.n_needed, self._identity, self._buffers = local, shard.n_cols, True, {}
+            self.recv_splits = self.send_splits = [shard.n_cols]
+            return
         cols = local.indices.to(torch.int64)
         needed = torch.unique(cols)                                  # sorted: grouped by owner
         new_cols = torch.searchsorted(needed, cols).to(torch.int32)
@@ -123,7 +129,6 @@ class HaloPlan(object):
         # tell every owner which of its rows this rank wants
         self.send_counts = torch.empty(world, dtype=torch.int64, device=dev)
         # a 1-rank process group still goes through the collectives (same code path as N ranks)
-        self._collective = world > 1 or (dist.is_initialized() and dist.get_world_size(group) == 1)
         if self._collective:
             all_to_all_rows(self.send_counts, self.recv_counts, group=group)
         else:
