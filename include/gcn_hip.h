@@ -129,8 +129,8 @@ int gcn_fill_synthetic_f32(int64_t count, uint64_t seed, float* out, void* strea
 
 typedef struct gcn_spmm_plan gcn_spmm_plan;
 
-/* Row-length analysis of one CSR structure: nnz-balanced strips for ordinary
- * rows, chunk table for rows longer than the split threshold.  [sync] */
+/* Row-length analysis of one CSR structure: work-balanced strips for ordinary
+ * rows, chunk tables for rows longer than the split thresholds.  [sync] */
 int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, gcn_spmm_plan** plan_out,
                          void* stream);
 int gcn_spmm_plan_destroy(gcn_spmm_plan* plan);
@@ -148,9 +148,10 @@ int gcn_spmm_plan_last_timing(const gcn_spmm_plan* plan, float* ms2);
 /* C[n_rows x f] = A . B, A in CSR, B [n_cols x f]: `dot(x, y, sparse=True)`
  * = tf.sparse_tensor_dense_matmul at gcn/layers.py:28-31, called at
  * layers.py:202 (A_hat . (XW)) and layers.py:198-199 (X . W0).  Every output row
- * of at most `split threshold` (256) nonzeros is accumulated sequentially in
- * storage order with a separate float32 multiply and add (the order of the serial
- * CPU loop); longer rows are summed in fixed-size chunks, then chunk by chunk. */
+ * up to the split threshold (256 nonzeros when f <= 64, 1024 for wider operands or with
+ * GCN_SPLIT_WIDE) is accumulated sequentially in storage order with a separate float32
+ * multiply and add -- the order and the bits of the serial CPU loop; a longer row is summed
+ * in chunks of that many entries whose partial rows are then added in chunk order. */
 int gcn_spmm_csr_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
                      int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
                      size_t workspace_bytes, void* stream);
