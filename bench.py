@@ -307,7 +307,10 @@ def main():
         else:
             del op
         torch.cuda.empty_cache()
-        epoch = rmat_epoch_ms(shard, b_local, world)
+        try:
+            epoch = rmat_epoch_ms(shard, b_local, world)
+        except Exception as exc:            # the product's line above stays valid whatever happens here
+            epoch = {'error': '%s: %s' % (type(exc).__name__, exc)}
     if rank == 0:
         if epoch is not None:
             line['gcn_epoch_rmat'] = epoch
