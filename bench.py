@@ -293,8 +293,12 @@ def main():
             line['cpu_baseline_all_cores'] = allcores
             line['parity_sample'] = check
         if world == 1 and not args.no_epoch:
-            line['gcn_epoch'] = [planetoid_epoch_ms('cora'), planetoid_epoch_ms('citeseer'),
-                                 planetoid_epoch_ms('cora', hip_graph=True), planetoid_epoch_ms('citeseer', hip_graph=True)]
+            line['gcn_epoch'] = []
+            for name, recorded in (('cora', False), ('citeseer', False), ('cora', True), ('citeseer', True)):
+                try:
+                    line['gcn_epoch'].append(planetoid_epoch_ms(name, hip_graph=recorded))
+                except Exception as exc:
+                    line['gcn_epoch'].append({'dataset': name, 'error': '%s: %s' % (type(exc).__name__, exc)})
         t = line['roofline']['traffic']
         if t:
             line['hbm_measured_gbps'] = t / (row_ms * 1e-3) / 1e9
