@@ -218,6 +218,76 @@ __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const i
     }
 }
 
+// The same sums with two batches of B rows in flight (more registers, lower occupancy): for matrices too
+// small to hide latency with occupancy, where the longest row's chain of dependent batches ends the kernel.
+template <int VEC, int VPL, bool DROPOUT>
+__device__ __forceinline__ void accumulate_range_piped(int64_t k0, int64_t k1, const int32_t* __restrict__ indices,
+                                                 const float* __restrict__ vals, const float* __restrict__ b,
+                                                 uint32_t ldb, const int (&lcol)[VPL], const DropArgs& dr,
+                                                 float (&acc)[VPL][VEC]) {
+    if (k0 >= k1) return;
+    const int64_t k_last = k1 - 1;
+    uint32_t c[kUnroll];
+    float a[kUnroll];
+    int64_t id[kUnroll];
+    auto fetch_entries = [&](int64_t kb) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
+            c[u] = (uint32_t)indices[ku];
+            a[u] = vals[ku];
+            if (DROPOUT) id[u] = dr.perm ? dr.perm[ku] : ku;
+        }
+    };
+    // two batches of B rows in flight: while batch n is added, the rows of batch n+1 are on their way and
+    // the entries of batch n+2 are being fetched -- a long row is a chain of dependent batches, and this
+    // halves the number of memory latencies it pays
+    float bv[2][kUnroll][VPL][VEC];
+    float a_b[2][kUnroll];
+    bool kept[2][kUnroll];
+    auto issue_rows = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const float* brow = b + (uint64_t)c[u] * (uint64_t)ldb;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) load_vec<VEC>(brow + lcol[v], bv[s][u][v]);
+            a_b[s][u] = a[u];
+            kept[s][u] = true;
+            if (DROPOUT) {
+                kept[s][u] = keep_entry(dr.key, (uint64_t)id[u], dr.keep_prob);
+                a_b[s][u] = __fmul_rn(a[u], dr.inv_keep);
+            }
+        }
+    };
+    auto add_batch = [&](int s, int64_t rem) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (u < rem && kept[s][u]) {
+#pragma unroll
+                for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        acc[v][e] = __fadd_rn(acc[v][e], __fmul_rn(a_b[s][u], bv[s][u][v][e]));
+            }
+        }
+    };
+    fetch_entries(k0);
+    issue_rows(0);
+    fetch_entries(k0 + kUnroll);
+    for (int64_t k = k0;;) {
+        issue_rows(1);
+        fetch_entries(k + 2 * kUnroll);
+        add_batch(0, k1 - k);
+        k += kUnroll;
+        if (k >= k1) break;
+        issue_rows(0);
+        fetch_entries(k + 2 * kUnroll);
+        add_batch(1, k1 - k);
+        k += kUnroll;
+        if (k >= k1) break;
+    }
+}
+
 // out = act(acc + addend): the addend row (may be null) is the "+ X" of a smoothing step
 template <int VEC, int VPL>
 __device__ __forceinline__ void store_row(float* dst, const float* addend, const int (&col)[VPL],
@@ -240,7 +310,7 @@ __device__ __forceinline__ void store_row(float* dst, const float* addend, const
 }
 
 // rows of ordinary length; one wave per strip
-template <int LPR, int VEC, int VPL, bool DROPOUT>
+template <int LPR, int VEC, int VPL, bool DROPOUT, bool PIPED>
 __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, const int32_t* __restrict__ strip_row,
                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
@@ -275,7 +345,10 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
             for (int v = 0; v < VPL; ++v)
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
-            accumulate_range<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
+            if (PIPED)
+                accumulate_range_piped<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
+            else
+                accumulate_range<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
             store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
                                 relu != 0);
         }
@@ -478,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
         chunks_block<LPR, VEC, VPL, DROPOUT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
                                              indices, vals, f, b, ldb, part, ldp, dr, pv.split);
     else if (LPR >= 32)
-        strips_block<LPR, VEC, VPL, DROPOUT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
+        strips_block<LPR, VEC, VPL, DROPOUT, (U > kUnroll)>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
                                              vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd);
     else
         slots_block<LPR, VEC, VPL, DROPOUT, U>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
@@ -612,6 +685,11 @@ static int launch_by_width(const SpmmCall& a) {
     if (nvec <= 4) return launch_variant<4, VEC, 1, DROPOUT>(a);
     if (nvec <= 8) return launch_variant<8, VEC, 1, DROPOUT>(a);
     if (nvec <= 16) return launch_variant<16, VEC, 1, DROPOUT>(a);
+    if (a.plan->strip_nnz < kStripNnz) {  // small matrix, wide operand: two batches of B rows in flight per row
+        if (nvec <= 32) return launch_variant<32, VEC, 1, DROPOUT, kUnrollSmall>(a);
+        if (nvec <= 64) return launch_variant<64, VEC, 1, DROPOUT, kUnrollSmall>(a);
+        return launch_variant<64, VEC, 2, DROPOUT, kUnrollSmall>(a);
+    }
     if (nvec <= 32) return launch_variant<32, VEC, 1, DROPOUT>(a);
     if (nvec <= 64) return launch_variant<64, VEC, 1, DROPOUT>(a);
     return launch_variant<64, VEC, 2, DROPOUT>(a);  // wider rows: passes of 128 vectors
