@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument('--no-epoch', action='store_true', help='skip the Planetoid epoch-time leg')
     ap.add_argument('--chunks', type=int, default=4,
                     help='N>1: ranges of feature columns the exchange is pipelined over (1 = no overlap)')
+    ap.add_argument('--no-autotune', action='store_true',
+                    help='N>1: keep the --chunks progressive ranges instead of timing the candidate splits')
     ap.add_argument('--allgather', action='store_true',
                     help='N > 1: all-gather the whole of B instead of exchanging only the referenced rows')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
@@ -108,7 +110,7 @@ def planetoid_epoch_ms(name, epochs=60, hip_graph=False):
             'train_step': 'one HIP graph' if hip_graph else 'eager launches'}
 
 
-def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, classes=16):
+def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, classes=16, chunks=4):
     """One training step (forward + backward + Adam, train.py:203-205) of a 2-layer GCN
     features -> hidden -> classes on the bench graph, rows sharded over the ranks."""
     import torch
@@ -119,7 +121,7 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, cl
     mask = (rows % 64 == 0).to(torch.int32)
     del rows
     model = ShardedGCN(shard, x_local.shape[1], [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
-                       seed=123)
+                       seed=123, chunks=chunks)
     for _ in range(warmup):
         model.train_step(x_local, labels, mask)
     if group_world > 1:
@@ -231,6 +233,10 @@ def main():
         torch.cuda.empty_cache()
         op = gdist.HaloSpmm(shard, f, chunks=args.chunks) if not args.allgather else gdist.AllGatherSpmm(shard, f)
         a = op.compact if not args.allgather else shard.local
+        tuned = None
+        if not args.allgather and not args.no_autotune:
+            # which split of the feature columns pipelines best on this communicator: measured once
+            tuned = op.autotune(b_local)
         a.plan.set_timing(True)
 
         def step():
@@ -278,7 +284,7 @@ def main():
             'config': {'workload': 'A_hat.B, R-MAT scale %d edge factor %d (+I, sym-normalised), F=%d'
                                    % (args.scale, args.edge_factor, f),
                        'n_nodes': n, 'nnz': nnz, 'features': f,
-                       'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B in %d progressive column ranges, overlapped with the product' % args.chunks)) if world > 1 else 'single GPU'},
+                       'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B pipelined over column ranges %s' % (op.ranges,))) if world > 1 else 'single GPU'},
             'pct_of_hbm_peak': 100.0 * value / (HBM_PEAK_GBPS * world),
             'gather_gbps': total_gather / (ms_per_step * 1e-3) / 1e9,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -286,6 +292,7 @@ def main():
                          'traffic': measured_traffic('spmm_rows_kernel', args.scale, args.edge_factor, f, world),
                          'kernel': 'spmm_rows_kernel', 'kernel_ms': row_ms, 'reduce_kernel_ms': red_ms,
                          'algorithmic_bytes': local_min, 'launch_features': f_launch},
+            'pipeline_candidates_ms': ([{'ranges': r, 'ms': t} for r, t in tuned] if (world > 1 and tuned) else None),
         }
         if world == 1 and not args.no_cpu_baseline:
             base, allcores, check = cpu_baseline(a, b_full, c, args.cpu_row_stride)
@@ -302,6 +309,7 @@ def main():
         t = line['roofline']['traffic']
         if t:
             line['hbm_measured_gbps'] = t / (row_ms * 1e-3) / 1e9
+    ranges_used = list(op.ranges) if (world > 1 and not args.allgather) else None
     # GCN epoch on the same graph, every rank takes part
     epoch = None
     if not args.no_epoch:
@@ -312,7 +320,10 @@ def main():
             del op
         torch.cuda.empty_cache()
         try:
-            epoch = rmat_epoch_ms(shard, b_local, world)
+            shares = args.chunks
+            if world > 1 and not args.allgather:
+                shares = tuple(hi - lo for lo, hi in ranges_used)
+            epoch = rmat_epoch_ms(shard, b_local, world, chunks=shares)
         except Exception as exc:            # the product's line above stays valid whatever happens here
             epoch = {'error': '%s: %s' % (type(exc).__name__, exc)}
     if rank == 0:

@@ -103,7 +103,7 @@ class HaloPlan(object):
     not change, so sums are bit-identical), and the ranks exchange their request lists.
     ``exchange(b_local)`` then gathers the requested local rows and moves them with one
     ``all_to_all_single``.  On a skewed graph most vertices have few neighbours, so a shard
-    references a fraction of the columns (about a quarter at 8 ranks on the scale-24 R-MAT) and
+    references a fraction of the columns (72 / 52 / 37 % at 2 / 4 / 8 ranks on the scale-24 R-MAT) and
     the exchange moves that fraction of what an all-gather moves."""
 
     def __init__(self, shard, group=None, csr_factory=None):
@@ -145,6 +145,11 @@ class HaloPlan(object):
         self.n_needed = int(needed.numel())
         self._identity = (not self._collective) and self.n_needed == shard.n_cols == local.n_rows
         self._buffers = {}
+
+    def drop_buffers(self, keep_widths=()):
+        """Free the cached send / receive buffers of every width not in ``keep_widths``."""
+        for key in [k for k in self._buffers if k[0] not in keep_widths]:
+            del self._buffers[key]
 
     def exchange(self, b_local, slot=0, async_op=False):
         """Rows of the global matrix this rank's shard references, [n_needed x f], in column order.
@@ -235,6 +240,55 @@ class HaloSpmm(object):
 
     def __call__(self, b_local, relu=False):
         return halo_product(self.plan, b_local, self.c_local, relu, self.ranges, self._spmm)
+
+    # width shares of the candidate pipelines: how long the first (exposed) exchange is against how
+    # much the narrower products cost depends on the ratio of link to memory speed, which differs
+    # between 2, 4 and 8 ranks -- so it is measured, not assumed
+    CANDIDATES = ((1,), (1, 3), (1, 1), (1, 1, 2), (1, 1, 2, 4), (1, 1, 1, 1))
+
+    def autotune(self, b_local, reps=2, clock=None):
+        """Time every candidate split of the feature columns on this communicator (max over the ranks,
+        so that every rank picks the same one) and keep the fastest.  Returns [(ranges, ms), ...]."""
+        import time
+        world = self.shard.world
+        clock = clock or time.perf_counter
+        seen, results = set(), []
+        for shares in self.CANDIDATES:
+            ranges = column_shares(self.f, shares)
+            if tuple(ranges) in seen:
+                continue
+            seen.add(tuple(ranges))
+            self.ranges = ranges
+            self(b_local)                                            # buffers of these widths, untimed
+            if world > 1:
+                dist.barrier(group=self.plan.group)
+            if b_local.is_cuda:
+                torch.cuda.synchronize()
+            t0 = clock()
+            for _ in range(reps):
+                self(b_local)
+            if b_local.is_cuda:
+                torch.cuda.synchronize()
+            ms = torch.tensor([(clock() - t0) / reps * 1e3], dtype=torch.float64)
+            if world > 1:
+                ms = ms.to(b_local.device) if dist.get_backend(self.plan.group) != 'gloo' else ms
+                dist.all_reduce(ms, op=dist.ReduceOp.MAX, group=self.plan.group)
+            results.append((ranges, float(ms.item())))
+        self.ranges = min(results, key=lambda r: r[1])[0]
+        self.plan.drop_buffers(keep_widths={hi - lo for lo, hi in self.ranges})
+        return results
+
+
+def column_shares(f, shares):
+    """Contiguous column ranges of f columns with widths in the proportions ``shares`` (multiples of 4)."""
+    quads = (f + 3) // 4
+    total = sum(shares)
+    edges, acc = [0], 0
+    for share in shares:
+        acc += share
+        edges.append(min(f, 4 * ((quads * acc) // total)))
+    edges[-1] = f
+    return [(lo, hi) for lo, hi in zip(edges, edges[1:]) if hi > lo]
 
 
 def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None):

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import graph, sparse
-from .dist import HaloPlan, all_reduce_sum, column_chunks, halo_product
+from .dist import HaloPlan, all_reduce_sum, column_chunks, column_shares, halo_product
 from .layers import _GemmFn
 from .models import TfAdam
 
@@ -19,7 +19,13 @@ from .models import TfAdam
 def _product(plan, b_local, relu, chunks):
     """A_local . exchange(B) into a fresh tensor; wide operands pipeline the exchange over column ranges."""
     out = torch.empty((plan.compact.n_rows, b_local.shape[1]), dtype=torch.float32, device=b_local.device)
-    ranges = column_chunks(b_local.shape[1], chunks if b_local.shape[1] >= 128 else 1)
+    f = b_local.shape[1]
+    if f < 128:
+        ranges = [(0, f)]
+    elif isinstance(chunks, (tuple, list)):           # width shares, e.g. the ones HaloSpmm.autotune picked
+        ranges = column_shares(f, chunks)
+    else:
+        ranges = column_chunks(f, chunks)
     return halo_product(plan, b_local, out, relu, ranges)
 
 
@@ -69,7 +75,8 @@ class ShardedGCN(object):
     def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
                  seed=0, group=None, chunks=4):
         self.shard, self.group = shard, group
-        self.chunks = chunks if shard.world > 1 else 1      # ranges of feature columns an exchange is pipelined over
+        # ranges of feature columns an exchange is pipelined over: a count, or a tuple of width shares
+        self.chunks = chunks if shard.world > 1 else 1
         self.plan = HaloPlan(shard, group=group)
         self.dropout, self.wd, self.seed = float(dropout), float(weight_decay), int(seed)
         sizes = [f_in] + list(layer_size) + [n_classes]

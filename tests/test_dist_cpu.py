@@ -72,6 +72,17 @@ def _worker(rank, world, port, result_dir):
         piped = gdist.HaloSpmm(shard, f, spmm=_oracle_spmm, plan=halo.plan, chunks=3)
         assert piped.ranges == [(0, 4), (4, 8), (8, 16)]
         assert torch.equal(piped(torch.from_numpy(b[r0:r1].copy()), relu=True), c_local)
+        # the pipeline is picked by measurement; a rigged clock makes the choice predictable, the
+        # MAX over ranks makes it the same everywhere, and the result does not change
+        ticks = iter(range(1000))
+        fake = {'t': 0.0}
+
+        def clock():
+            fake['t'] += next(ticks) * (1.0 + rank)          # later candidates look slower, on every rank
+            return fake['t']
+        timings = piped.autotune(torch.from_numpy(b[r0:r1].copy()), reps=1, clock=clock)
+        assert len(timings) >= 3 and piped.ranges == timings[0][0] == [(0, f)]
+        assert torch.equal(piped(torch.from_numpy(b[r0:r1].copy()), relu=True), c_local)
         # the MAX-over-ranks timing reduction bench.py uses
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
