@@ -85,6 +85,9 @@ def _single_rank_rccl_worker(rank, port, result_dir):
         for _ in range(3):                         # buffers are reused across calls
             got = piped(b, relu=True)
             assert torch.equal(got, ref)
+        timings = piped.autotune(b)                # every candidate split runs over RCCL; the fastest is kept
+        assert len(timings) == len(gdist.HaloSpmm.CANDIDATES) and piped.ranges in [r for r, _ in timings]
+        assert torch.equal(piped(b, relu=True), ref)
         gathered = gdist.AllGatherSpmm(shard, f)(b, relu=True)
         assert torch.equal(gathered, ref)
         t = torch.ones(4, device='cuda')
