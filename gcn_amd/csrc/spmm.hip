@@ -356,14 +356,21 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
 }
 
 // rows of ordinary length, narrow dense operand: a wave owns 64/LPR consecutive strips; each lane
-// group takes the next unclaimed row of that range when it has finished its own
+// group takes the next unclaimed row of that range when it is about to finish its own.
+//  - The claim is made one batch EARLY (while the last batch of the current row is in flight) and the
+//    first (column, value) batch of the claimed row is fetched then, so that a group switching rows has
+//    its entries in registers already: waits are wave-wide, and a wave of 16 groups over 50-entry rows
+//    has some group switching in almost every turn -- fetching at the switch made every turn pay two
+//    dependent memory latencies instead of one.
+//  - Row pointers come from a register window (indptr of 64 consecutive rows, one per lane, read with
+//    a cross-lane shuffle), not from memory at claim time.
 template <int LPR, int VEC, int VPL, bool DROPOUT, int kUnroll>
 __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, const int32_t* __restrict__ strip_row,
                                             const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                             const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                             uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
                                             const DropArgs& dr, int split, const float* __restrict__ add,
-                                            int64_t ldadd) {
+                                            int64_t ldadd, int64_t nnz) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
@@ -375,6 +382,46 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
     const int64_t s1 = (s0 + kGroups < n_strips) ? s0 + kGroups : n_strips;
     const int r_lo = strip_row[s0];
     const int r_hi = strip_row[s1];
+    // A batch is read as whole 16-byte vectors starting at its first entry (4-byte aligned: the
+    // hardware takes it), entries past the row's end included -- they are valid entries of later rows
+    // and are never added.  Only a wave whose rows end within one batch of the end of the arrays
+    // reads entry by entry with clamped addresses instead (wave-uniform choice).
+    const bool whole_batches = __builtin_amdgcn_readfirstlane((int)(indptr[r_hi] + kUnroll <= nnz)) != 0;
+    auto fetch_batch = [&](int64_t kb, int64_t k_last, uint32_t (&ci)[kUnroll], float (&av)[kUnroll],
+                           uint64_t (&idv)[kUnroll]) {
+        if (whole_batches) {
+#pragma unroll
+            for (int q = 0; q < kUnroll / 4; ++q) {
+                int4 iv;
+                float4 fv;
+                __builtin_memcpy(&iv, indices + kb + 4 * q, 16);
+                __builtin_memcpy(&fv, vals + kb + 4 * q, 16);
+                ci[4 * q + 0] = (uint32_t)iv.x;
+                ci[4 * q + 1] = (uint32_t)iv.y;
+                ci[4 * q + 2] = (uint32_t)iv.z;
+                ci[4 * q + 3] = (uint32_t)iv.w;
+                av[4 * q + 0] = fv.x;
+                av[4 * q + 1] = fv.y;
+                av[4 * q + 2] = fv.z;
+                av[4 * q + 3] = fv.w;
+            }
+            if (DROPOUT) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
+                    idv[u] = dr.perm ? (uint64_t)dr.perm[ku] : (uint64_t)ku;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
+                ci[u] = (uint32_t)indices[ku];
+                av[u] = vals[ku];
+                if (DROPOUT) idv[u] = dr.perm ? (uint64_t)dr.perm[ku] : (uint64_t)ku;
+            }
+        }
+    };
     uint64_t leaders = 0;  // lane 0 of every group
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) leaders |= 1ull << (g * LPR);
@@ -390,60 +437,58 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
             lcol[v] = on[v] ? col[v] : (int)f - VEC;
         }
         int r_next = r_lo;  // first unclaimed row (same in every lane)
-        int r = -1;         // row this group is summing; -1: none
+        bool live = true;   // the range may still hold a row for this group
+        // current row: r (-1: none), entries [k, k1), the batch at k in (cidx, a, id)
+        int r = -1;
         int64_t k = 0, k1 = 0;
-        bool live = true;  // the range may still hold a row for this group
+        uint32_t cidx[kUnroll];
+        float a[kUnroll];
+        uint64_t id[kUnroll];
+        // claimed row: its first batch is on its way
+        bool have_next = false;
+        int rn_row = -1;
+        int64_t nk = 0, nk1 = 0;
+        uint32_t ncidx[kUnroll];
+        float na[kUnroll];
+        uint64_t nid[kUnroll];
         float acc[VPL][VEC];
 #pragma unroll
         for (int v = 0; v < VPL; ++v)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
-        // (column, value, entry id) of the batch at k: loaded when the row is taken, and for the next
-        // batch while the B rows of the current one are in flight
-        uint32_t cidx[kUnroll];
-        float a[kUnroll];
-        uint64_t id[kUnroll];
-        auto fetch_batch = [&](int64_t kb, int64_t k_last) {
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
-                cidx[u] = (uint32_t)indices[ku];
-                a[u] = vals[ku];
-                if (DROPOUT) id[u] = dr.perm ? (uint64_t)dr.perm[ku] : (uint64_t)ku;
-            }
-        };
+        // register window of row pointers: lane l holds indptr[w_base + l] and indptr[w_base + l + 1]
+        int w_base = r_lo;
+        int64_t ip_lo = indptr[(w_base + lane < r_hi) ? w_base + lane : r_hi];
+        int64_t ip_hi = indptr[(w_base + lane + 1 < r_hi) ? w_base + lane + 1 : r_hi];
         for (;;) {
-            const bool idle = live && (k >= k1);
-            const uint64_t m = __ballot(idle) & leaders;
-            if (idle) {
-                if (r >= 0)
-                    store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
-                                        relu != 0);
-                const int rn = r_next + __popcll(m & below);
-                r = -1;
-                k = 0;
-                k1 = 0;
+            // ---- claims: groups without a claimed row whose current row ends with this batch (or is none)
+            if (r_next - w_base > 64 - kGroups) {  // wave-uniform: keep the rows claimable this turn inside the window
+                w_base = r_next;
+                ip_lo = indptr[(w_base + lane < r_hi) ? w_base + lane : r_hi];
+                ip_hi = indptr[(w_base + lane + 1 < r_hi) ? w_base + lane + 1 : r_hi];
+            }
+            const bool want = live && !have_next && (k + kUnroll >= k1);
+            const uint64_t m = __ballot(want) & leaders;
+            const int rn = r_next + __popcll(m & below);
+            r_next += __popcll(m);
+            // every lane takes part in the shuffles; only claimers use what they return
+            const int src = (want && rn < r_hi) ? rn - w_base : 0;
+            const int64_t a0 = __shfl(ip_lo, src);
+            const int64_t a1 = __shfl(ip_hi, src);
+            if (want) {
                 if (rn < r_hi) {
-                    const int64_t a0 = indptr[rn];
-                    const int64_t a1 = indptr[rn + 1];
-                    if (a1 - a0 <= split && a1 > a0) {  // longer rows are summed chunk-wise
-                        r = rn;
-                        k = a0;
-                        k1 = a1;
-                        fetch_batch(a0, a1 - 1);
-                    } else if (a1 == a0) {
-                        r = rn;  // empty row: stored as zeros (or the addend) on the next turn
+                    if (a1 - a0 <= split) {  // longer rows are summed chunk-wise: nothing to claim
+                        have_next = true;
+                        rn_row = rn;
+                        nk = a0;
+                        nk1 = a1;
+                        if (a1 > a0) fetch_batch(a0, a1 - 1, ncidx, na, nid);
                     }
-#pragma unroll
-                    for (int v = 0; v < VPL; ++v)
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
                 } else {
                     live = false;
                 }
             }
-            r_next += __popcll(m);
-            if (__ballot(live) == 0) break;
+            // ---- one batch of the current row
             if (k < k1) {
                 const int64_t k_last = k1 - 1;
                 const int64_t rem = k1 - k;
@@ -466,7 +511,7 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                     }
                 }
                 const int64_t kn = k + kUnroll;
-                if (kn < k1) fetch_batch(kn, k_last);
+                if (kn < k1) fetch_batch(kn, k_last, cidx, a, id);  // the same row goes on: its next batch
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     if (u < rem && kept[u]) {
@@ -479,6 +524,33 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                 }
                 k = kn;
             }
+            // ---- row finished (or none): store it, move to the claimed one
+            if (k >= k1) {
+                if (r >= 0) {
+                    store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
+                                        relu != 0);
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
+                }
+                r = -1;
+                k = 0;
+                k1 = 0;
+                if (have_next) {
+                    r = rn_row;
+                    k = nk;
+                    k1 = nk1;
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) {
+                        cidx[u] = ncidx[u];
+                        a[u] = na[u];
+                        if (DROPOUT) id[u] = nid[u];
+                    }
+                    have_next = false;
+                }
+            }
+            if (__ballot(live || r >= 0) == 0) break;
         }
     }
 }
@@ -526,7 +598,7 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
 }
 
 struct PlanView {
-    int64_t n_strips, n_chunks, chunk_blocks;
+    int64_t n_strips, n_chunks, chunk_blocks, nnz;
     int split;
     const int32_t* strip_row;
     const int32_t* chunk_long;
@@ -555,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
                                              vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd);
     else
         slots_block<LPR, VEC, VPL, DROPOUT, U>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
-                                            vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd);
+                                            vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd, pv.nnz);
 }
 
 // partial rows of each long row, added in chunk order; one wave per long row.  Partial rows are
@@ -644,6 +716,7 @@ static int launch_variant(const SpmmCall& a) {
     const gcn_spmm_plan::LongTable& lt = p->table[ti];
     PlanView pv;
     pv.n_strips = p->n_strips;
+    pv.nnz = p->nnz;
     pv.n_chunks = lt.n_chunks;
     pv.chunk_blocks = ceil_div(ceil_div(lt.n_chunks, kGroups), kWaves);
     pv.split = split_of(ti);
