@@ -506,7 +506,15 @@ __global__ void reduce_splits_kernel(int64_t k, int64_t n, int64_t splits, const
     const int64_t total = k * n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.0f;
-        for (int64_t p = 0; p < splits; ++p) s = __fadd_rn(s, part[p * total + i]);
+        int64_t p = 0;
+        for (; p + 8 <= splits; p += 8) {  // 8 independent loads in flight, added in range order
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = part[(p + u) * total + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = __fadd_rn(s, x[u]);
+        }
+        for (; p < splits; ++p) s = __fadd_rn(s, part[p * total + i]);
         c[(i / n) * ldc + (i % n)] = s;
     }
 }
