@@ -25,6 +25,7 @@ struct gcn_spmm_plan {
     int64_t n_rows, n_cols, nnz;
     int64_t n_strips;
     int strip_nnz;       // entries per strip
+    int chunk_len;       // entries per chunk of a long row; 0: the split threshold itself
     int device;
     int32_t* strip_row;  // [n_strips + 1] first row starting in each strip
     // rows longer than the split threshold, cut in chunks of that many entries; table 0 serves narrow
@@ -43,6 +44,7 @@ namespace gcn {
 
 constexpr int kStripNnz = 256;       // entries per strip on a matrix large enough to fill the chip with such strips
 constexpr int kStripNnzMin = 16;
+constexpr int kChunkSmall = 64;
 constexpr int kRowCost = 4;          // a row's fixed cost (pointer loads, store) in units of one entry
 constexpr int64_t kStripsWanted = 8192;  // 8 waves on each of the 1024 SIMDs
 
@@ -154,28 +156,62 @@ struct DropArgs {
     uint64_t seed, stream_id;
 };
 
+// sparse_dropout decisions of one batch of U entries starting at kb, for a lane group of LPR lanes.
+// Every lane of a group needs all U decisions, but a decision costs a 64-bit hash: lane `sub` of the
+// group hashes only entries sub, sub + LPR, ... and a wave ballot hands the bits round.
+// entry_ids: this lane's entries' ids (perm[k] or k), fetched with the batch.
+template <int LPR, int U>
+struct DropIds {
+    static constexpr int kRounds = (U + LPR - 1) / LPR;
+    uint64_t v[kRounds];
+};
+
+template <int LPR, int U>
+__device__ __forceinline__ void fetch_drop_ids(const DropArgs& dr, int64_t kb, int64_t k_last, int sub,
+                                               DropIds<LPR, U>& ids) {
+#pragma unroll
+    for (int j = 0; j < DropIds<LPR, U>::kRounds; ++j) {
+        const int64_t kj = kb + j * LPR + sub;
+        const int64_t ku = kj < k_last ? kj : k_last;
+        ids.v[j] = dr.perm ? (uint64_t)dr.perm[ku] : (uint64_t)ku;
+    }
+}
+
+template <int LPR, int U>
+__device__ __forceinline__ void drop_decisions(const DropArgs& dr, const DropIds<LPR, U>& ids, int group_base,
+                                               bool (&kept)[U]) {
+#pragma unroll
+    for (int j = 0; j < DropIds<LPR, U>::kRounds; ++j) {
+        const uint64_t bits = __ballot(keep_entry(dr.key, ids.v[j], dr.keep_prob));
+#pragma unroll
+        for (int i = 0; i < LPR; ++i)
+            if (j * LPR + i < U) kept[j * LPR + i] = (bits >> (group_base + i)) & 1ull;
+    }
+}
+
 // acc += sum over entries k0..k1-1 (in order) of a_k * B[col_k, this lane's columns].
 // Entries are taken kUnroll at a time: the B rows of one batch and the (index, value) pairs of the
 // next batch are all in flight together.  Addresses past the end of the range are clamped to its
 // last entry (a valid, cached address) so that no load sits behind a branch; what such a slot
 // loads is never added.
-template <int VEC, int VPL, bool DROPOUT>
+template <int LPR, int VEC, int VPL, bool DROPOUT>
 __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const int32_t* __restrict__ indices,
                                                  const float* __restrict__ vals, const float* __restrict__ b,
                                                  uint32_t ldb, const int (&lcol)[VPL], const DropArgs& dr,
                                                  float (&acc)[VPL][VEC]) {
     if (k0 >= k1) return;
     const int64_t k_last = k1 - 1;
+    const int sub = (threadIdx.x & 63) % LPR, group_base = (threadIdx.x & 63) - sub;
     uint32_t c[kUnroll];
     float a[kUnroll];
-    int64_t id[kUnroll];
+    DropIds<LPR, kUnroll> ids;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
         const int64_t ku = (k0 + u < k_last) ? k0 + u : k_last;
         c[u] = (uint32_t)indices[ku];
         a[u] = vals[ku];
-        if (DROPOUT) id[u] = dr.perm ? dr.perm[ku] : ku;
     }
+    if (DROPOUT) fetch_drop_ids<LPR, kUnroll>(dr, k0, k_last, sub, ids);
     for (int64_t k = k0;; k += kUnroll) {
         float bv[kUnroll][VPL][VEC];
 #pragma unroll
@@ -188,13 +224,10 @@ __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const i
         bool kept[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            a_now[u] = a[u];
+            a_now[u] = DROPOUT ? __fmul_rn(a[u], dr.inv_keep) : a[u];
             kept[u] = true;
-            if (DROPOUT) {
-                kept[u] = keep_entry(dr.key, (uint64_t)id[u], dr.keep_prob);
-                a_now[u] = __fmul_rn(a[u], dr.inv_keep);
-            }
         }
+        if (DROPOUT) drop_decisions<LPR, kUnroll>(dr, ids, group_base, kept);
         // (index, value) pairs of the next batch
         const int64_t kn = k + kUnroll;
 #pragma unroll
@@ -202,8 +235,8 @@ __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const i
             const int64_t ku = (kn + u < k_last) ? kn + u : k_last;
             c[u] = (uint32_t)indices[ku];
             a[u] = vals[ku];
-            if (DROPOUT) id[u] = dr.perm ? dr.perm[ku] : ku;
         }
+        if (DROPOUT) fetch_drop_ids<LPR, kUnroll>(dr, kn, k_last, sub, ids);
         const int64_t rem = k1 - k;
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -220,24 +253,25 @@ __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const i
 
 // The same sums with two batches of B rows in flight (more registers, lower occupancy): for matrices too
 // small to hide latency with occupancy, where the longest row's chain of dependent batches ends the kernel.
-template <int VEC, int VPL, bool DROPOUT>
+template <int LPR, int VEC, int VPL, bool DROPOUT>
 __device__ __forceinline__ void accumulate_range_piped(int64_t k0, int64_t k1, const int32_t* __restrict__ indices,
                                                  const float* __restrict__ vals, const float* __restrict__ b,
                                                  uint32_t ldb, const int (&lcol)[VPL], const DropArgs& dr,
                                                  float (&acc)[VPL][VEC]) {
     if (k0 >= k1) return;
     const int64_t k_last = k1 - 1;
+    const int sub = (threadIdx.x & 63) % LPR, group_base = (threadIdx.x & 63) - sub;
     uint32_t c[kUnroll];
     float a[kUnroll];
-    int64_t id[kUnroll];
+    DropIds<LPR, kUnroll> ids;
     auto fetch_entries = [&](int64_t kb) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
             c[u] = (uint32_t)indices[ku];
             a[u] = vals[ku];
-            if (DROPOUT) id[u] = dr.perm ? dr.perm[ku] : ku;
         }
+        if (DROPOUT) fetch_drop_ids<LPR, kUnroll>(dr, kb, k_last, sub, ids);
     };
     // two batches of B rows in flight: while batch n is added, the rows of batch n+1 are on their way and
     // the entries of batch n+2 are being fetched -- a long row is a chain of dependent batches, and this
@@ -251,13 +285,10 @@ __device__ __forceinline__ void accumulate_range_piped(int64_t k0, int64_t k1, c
             const float* brow = b + (uint64_t)c[u] * (uint64_t)ldb;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) load_vec<VEC>(brow + lcol[v], bv[s][u][v]);
-            a_b[s][u] = a[u];
+            a_b[s][u] = DROPOUT ? __fmul_rn(a[u], dr.inv_keep) : a[u];
             kept[s][u] = true;
-            if (DROPOUT) {
-                kept[s][u] = keep_entry(dr.key, (uint64_t)id[u], dr.keep_prob);
-                a_b[s][u] = __fmul_rn(a[u], dr.inv_keep);
-            }
         }
+        if (DROPOUT) drop_decisions<LPR, kUnroll>(dr, ids, group_base, kept[s]);
     };
     auto add_batch = [&](int s, int64_t rem) {
 #pragma unroll
@@ -346,9 +377,9 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
             if (PIPED)
-                accumulate_range_piped<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
+                accumulate_range_piped<LPR, VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
             else
-                accumulate_range<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
+                accumulate_range<LPR, VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
             store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
                                 relu != 0);
         }
@@ -388,7 +419,7 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
     // reads entry by entry with clamped addresses instead (wave-uniform choice).
     const bool whole_batches = __builtin_amdgcn_readfirstlane((int)(indptr[r_hi] + kUnroll <= nnz)) != 0;
     auto fetch_batch = [&](int64_t kb, int64_t k_last, uint32_t (&ci)[kUnroll], float (&av)[kUnroll],
-                           uint64_t (&idv)[kUnroll]) {
+                           DropIds<LPR, kUnroll>& idv) {
         if (whole_batches) {
 #pragma unroll
             for (int q = 0; q < kUnroll / 4; ++q) {
@@ -405,22 +436,15 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                 av[4 * q + 2] = fv.z;
                 av[4 * q + 3] = fv.w;
             }
-            if (DROPOUT) {
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-                    const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
-                    idv[u] = dr.perm ? (uint64_t)dr.perm[ku] : (uint64_t)ku;
-                }
-            }
         } else {
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
                 ci[u] = (uint32_t)indices[ku];
                 av[u] = vals[ku];
-                if (DROPOUT) idv[u] = dr.perm ? (uint64_t)dr.perm[ku] : (uint64_t)ku;
             }
         }
+        if (DROPOUT) fetch_drop_ids<LPR, kUnroll>(dr, kb, k_last, sub, idv);
     };
     uint64_t leaders = 0;  // lane 0 of every group
 #pragma unroll
@@ -443,14 +467,14 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
         int64_t k = 0, k1 = 0;
         uint32_t cidx[kUnroll];
         float a[kUnroll];
-        uint64_t id[kUnroll];
+        DropIds<LPR, kUnroll> id;
         // claimed row: its first batch is on its way
         bool have_next = false;
         int rn_row = -1;
         int64_t nk = 0, nk1 = 0;
         uint32_t ncidx[kUnroll];
         float na[kUnroll];
-        uint64_t nid[kUnroll];
+        DropIds<LPR, kUnroll> nid;
         float acc[VPL][VEC];
 #pragma unroll
         for (int v = 0; v < VPL; ++v)
@@ -503,13 +527,10 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                 bool kept[kUnroll];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
-                    a_now[u] = a[u];
+                    a_now[u] = DROPOUT ? __fmul_rn(a[u], dr.inv_keep) : a[u];
                     kept[u] = true;
-                    if (DROPOUT) {
-                        kept[u] = keep_entry(dr.key, id[u], dr.keep_prob);
-                        a_now[u] = __fmul_rn(a[u], dr.inv_keep);
-                    }
                 }
+                if (DROPOUT) drop_decisions<LPR, kUnroll>(dr, id, lane - sub, kept);
                 const int64_t kn = k + kUnroll;
                 if (kn < k1) fetch_batch(kn, k_last, cidx, a, id);  // the same row goes on: its next batch
 #pragma unroll
@@ -545,8 +566,8 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                     for (int u = 0; u < kUnroll; ++u) {
                         cidx[u] = ncidx[u];
                         a[u] = na[u];
-                        if (DROPOUT) id[u] = nid[u];
                     }
+                    if (DROPOUT) id = nid;
                     have_next = false;
                 }
             }
@@ -563,7 +584,7 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                              uint32_t ldb, float* __restrict__ part, int64_t ldp, const DropArgs& dr,
-                                             int split) {
+                                             int chunk_len) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
@@ -574,9 +595,9 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
     if (chunk >= n_chunks) return;
     const int li = chunk_long[chunk];
     const int r = long_row[li];
-    const int64_t k0 = indptr[r] + (chunk - long_chunk[li]) * (int64_t)split;
+    const int64_t k0 = indptr[r] + (chunk - long_chunk[li]) * (int64_t)chunk_len;
     const int64_t row_end = indptr[r + 1];
-    const int64_t k1 = (k0 + split < row_end) ? k0 + split : row_end;
+    const int64_t k1 = (k0 + chunk_len < row_end) ? k0 + chunk_len : row_end;
     for (int64_t col0 = 0; col0 < f; col0 += kTile) {
         int col[VPL];
         int lcol[VPL];
@@ -592,7 +613,7 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
         for (int v = 0; v < VPL; ++v)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
-        accumulate_range<VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
+        accumulate_range<LPR, VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
         store_row<VEC, VPL>(part + chunk * ldp, nullptr, col, on, acc, false);
     }
 }
@@ -600,6 +621,7 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
 struct PlanView {
     int64_t n_strips, n_chunks, chunk_blocks, nnz;
     int split;
+    int chunk_len;
     const int32_t* strip_row;
     const int32_t* chunk_long;
     const int32_t* long_row;
@@ -621,7 +643,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
     const int64_t block = blockIdx.x;
     if (block < pv.chunk_blocks)
         chunks_block<LPR, VEC, VPL, DROPOUT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
-                                             indices, vals, f, b, ldb, part, ldp, dr, pv.split);
+                                             indices, vals, f, b, ldb, part, ldp, dr, pv.chunk_len);
     else if (LPR >= 32)
         strips_block<LPR, VEC, VPL, DROPOUT, (U > kUnroll)>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
                                              vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd);
@@ -720,6 +742,7 @@ static int launch_variant(const SpmmCall& a) {
     pv.n_chunks = lt.n_chunks;
     pv.chunk_blocks = ceil_div(ceil_div(lt.n_chunks, kGroups), kWaves);
     pv.split = split_of(ti);
+    pv.chunk_len = p->chunk_len ? p->chunk_len : pv.split;
     pv.strip_row = p->strip_row;
     pv.chunk_long = lt.chunk_long;
     pv.long_row = lt.long_row;
@@ -838,6 +861,9 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
     p->nnz = nnz;
     const int64_t work = nnz + n_rows * kRowCost;
     p->strip_nnz = strip_nnz_for(work);
+    // on a small matrix a chunk is a chain of dependent batches like any row: keep it short (the rows it
+    // applies to are summed chunk-wise either way)
+    p->chunk_len = p->strip_nnz < kStripNnz ? kChunkSmall : 0;
     p->n_strips = std::max<int64_t>(1, ceil_div(work, p->strip_nnz));
     p->strip_row = nullptr;
     for (int t = 0; t < 2; ++t) {
@@ -915,7 +941,7 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
                     const int32_t slot = (int32_t)long_row.size();
                     long_row.push_back(rows[o]);
                     long_chunk.push_back(total);
-                    const int64_t nch = ceil_div(len, split);
+                    const int64_t nch = ceil_div(len, p->chunk_len ? (int64_t)p->chunk_len : split);
                     chunk_long.insert(chunk_long.end(), (size_t)nch, slot);
                     total += nch;
                 }
