@@ -150,10 +150,14 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
     float4 ra[kAPer], rb[kBPer];
     const int a_r = tid / kKQ, a_kq = (tid % kKQ) * 4;
 
-    auto load_fast = [&](int64_t k0) {
+    // loaders: A and B separately, so that a narrow output (n < BN: every tile is an edge tile in n) still
+    // streams A -- nearly all of the bytes -- without a bounds test per element
+    auto load_a_fast = [&](int64_t k0) {
 #pragma unroll
         for (int i = 0; i < kAPer; ++i)
             ra[i] = *reinterpret_cast<const float4*>(a + (m0 + a_r + kARows * i) * lda + k0 + a_kq);
+    };
+    auto load_b_fast = [&](int64_t k0) {
 #pragma unroll
         for (int p = 0; p < kBPer; ++p) {
             const int u = tid + kBlock * p;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
                 rb[p] = *reinterpret_cast<const float4*>(b + (k0 + u / (BN / 4)) * ldb + n0 + (u % (BN / 4)) * 4);
         }
     };
-    auto load_guarded = [&](int64_t k0) {
+    auto load_a_guarded = [&](int64_t k0) {
 #pragma unroll
         for (int i = 0; i < kAPer; ++i) {
             const int64_t gr = m0 + a_r + kARows * i;
@@ -178,6 +182,8 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
                 ra[i] = make_float4(t[0], t[1], t[2], t[3]);
             }
         }
+    };
+    auto load_b_guarded = [&](int64_t k0) {
 #pragma unroll
         for (int p = 0; p < kBPer; ++p) {
             const int u = tid + kBlock * p;
@@ -266,26 +272,47 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
     };
 
     const int64_t n_ktiles = (k + kBK - 1) / kBK;
-    const bool interior = (m0 + kBM <= m) && (n0 + BN <= n) && a_vec && b_vec;
-    const int64_t n_full = interior ? k / kBK : 0;  // leading k tiles that need no guards
+    const bool a_inside = (m0 + kBM <= m) && a_vec;      // the A tile needs no guards (full k tiles)
+    const bool b_inside = (n0 + BN <= n) && b_vec;
+    const bool interior = (m0 + kBM <= m) && (n0 + BN <= n);
+    const int64_t n_full = a_inside ? k / kBK : 0;       // leading k tiles whose A loads need no guards
     if (n_ktiles > 0) {
         if (n_full > 0)
-            load_fast(0);
+            load_a_fast(0);
         else
-            load_guarded(0);
+            load_a_guarded(0);
+        if (n_full > 0 && b_inside)
+            load_b_fast(0);
+        else
+            load_b_guarded(0);
         store_tile();
     }
     __syncthreads();
     int64_t t = 0;
-    for (; t + 1 < n_full; ++t) {  // the next tile needs no guards: a branch-free body
-        load_fast((t + 1) * kBK);
-        compute();
-        __syncthreads();
-        store_tile();
-        __syncthreads();
+    if (b_inside) {
+        for (; t + 1 < n_full; ++t) {  // the next tile needs no guards: a branch-free body
+            load_a_fast((t + 1) * kBK);
+            load_b_fast((t + 1) * kBK);
+            compute();
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
+    } else {
+        for (; t + 1 < n_full; ++t) {  // edge tile in n (a narrow output): only the small B tile is guarded
+            load_a_fast((t + 1) * kBK);
+            load_b_guarded((t + 1) * kBK);
+            compute();
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
     }
     for (; t < n_ktiles; ++t) {
-        if (t + 1 < n_ktiles) load_guarded((t + 1) * kBK);
+        if (t + 1 < n_ktiles) {
+            load_a_guarded((t + 1) * kBK);
+            load_b_guarded((t + 1) * kBK);
+        }
         compute();
         __syncthreads();
         if (t + 1 < n_ktiles) store_tile();
