@@ -232,11 +232,11 @@ def test_recorded_train_step_follows_the_eager_one():
 
 @pytest.mark.parametrize('name', ['cora', 'citeseer'])
 def test_test_accuracy_over_seeds_matches_the_oracle(name, oracle):
-    """8 seeds (weight init + dropout streams), 60 epochs each, the GPU model and the CPU oracle trained
+    """10 seeds (weight init + dropout streams), 60 epochs each, the GPU model and the CPU oracle trained
     side by side on the fixture's split: the test accuracies have the same mean to within one standard
     deviation (they are in fact nearly equal seed by seed: same masks, same Adam)."""
     gpu_acc, ref_acc = [], []
-    for seed in range(1, 9):
+    for seed in range(1, 11):
         fx, tf, model, ph, feed, ref, _ = _setup(name, oracle, seed=seed)
         labels, mask = fx['y_train'], fx['train_mask']
         feed = dict(feed)
