@@ -10,9 +10,70 @@ namespace gcn {
 
 constexpr int kBlock = 256;
 
-// One thread per node.  row_stats[i] = (CE_i * w_i, correct_i * w_i) with w_i = mask_i / mean(mask);
+// row_stats[i] = (CE_i * w_i, correct_i * w_i) with w_i = mask_i / mean(mask);
 // dlogits[i][c] = d(mean_i CE_i w_i) / d logits[i][c] = (softmax_ic * sum_c labels_ic - labels_ic) * w_i / n.
 // An all-zero label row (CiteSeer's padded nodes) has CE 0 and argmax 0, as TensorFlow gives.
+//
+// G lanes per node (the power of two that holds the classes), one class per lane: a wave reads and
+// writes 64 consecutive floats of the row-major matrices per instruction, and max / argmax / sums
+// are butterflies inside the lane group.  (One thread per node reads its row at a 4 c-byte stride
+// several times over: 7.8 ms on 2^24 x 16 logits against 0.7 ms for this form.)
+template <int G>
+__global__ void softmax_xent_group_kernel(int64_t n, int c, const float* __restrict__ logits, int64_t ldx,
+                                          const int32_t* __restrict__ labels, int64_t ldl,
+                                          const int32_t* __restrict__ mask, float mask_mean,
+                                          float* __restrict__ row_stats, float* __restrict__ dlogits, int64_t ldd) {
+    constexpr int kRows = 64 / G;                       // nodes per wave
+    const float inv_n = 1.0f / (float)n;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_groups = (n + kRows - 1) / kRows;
+    for (int64_t g = wave; g < n_groups; g += n_waves) {    // uniform per wave: every lane takes part in the shuffles
+        const int64_t i = g * kRows + lane / G;
+        const bool live = i < n && sub < c;
+        float x = live ? logits[i * ldx + sub] : -INFINITY;
+        int32_t lab = live ? labels[i * ldl + sub] : INT32_MIN;
+        float mx = x;
+        int arg_x = sub, arg_l = sub;
+        int32_t best_l = lab;
+        float lab_sum = live ? (float)lab : 0.0f;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) {
+            const float ov = __shfl_xor(mx, d);
+            const int oa = __shfl_xor(arg_x, d);
+            if (ov > mx || (ov == mx && oa < arg_x)) {      // first maximum wins, as argmax does
+                mx = ov;
+                arg_x = oa;
+            }
+            const int32_t ol = __shfl_xor(best_l, d);
+            const int ola = __shfl_xor(arg_l, d);
+            if (ol > best_l || (ol == best_l && ola < arg_l)) {
+                best_l = ol;
+                arg_l = ola;
+            }
+            lab_sum += __shfl_xor(lab_sum, d);
+        }
+        float s = live ? expf(x - mx) : 0.0f;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) s += __shfl_xor(s, d);
+        const float lse = mx + logf(s);
+        float ce = live ? (float)lab * (lse - x) : 0.0f;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) ce += __shfl_xor(ce, d);
+        if (i < n) {
+            const float w = (float)mask[i] / mask_mean;
+            if (sub == 0) {
+                row_stats[2 * i] = ce * w;
+                row_stats[2 * i + 1] = (arg_x == arg_l) ? w : 0.0f;
+            }
+            if (dlogits && sub < c) dlogits[i * ldd + sub] = (expf(x - lse) * lab_sum - (float)lab) * (w * inv_n);
+        }
+    }
+}
+
+// More than 64 classes: one thread per node.
 __global__ void softmax_xent_kernel(int64_t n, int c, const float* __restrict__ logits, int64_t ldx,
                                     const int32_t* __restrict__ labels, int64_t ldl,
                                     const int32_t* __restrict__ mask, float mask_mean,
@@ -54,6 +115,16 @@ __global__ void softmax_xent_kernel(int64_t n, int c, const float* __restrict__ 
     }
 }
 
+template <int G>
+static void launch_xent_group(int64_t n, int c, const float* logits, int64_t ldx, const int32_t* labels, int64_t ldl,
+                              const int32_t* mask, float mask_mean, float* row_stats, float* dlogits, int64_t ldd,
+                              hipStream_t stream) {
+    const int64_t n_groups = ceil_div(n, (int64_t)(64 / G));
+    const int64_t blocks = std::min<int64_t>(ceil_div(n_groups, (int64_t)(kBlock / 64)), 1 << 16);
+    softmax_xent_group_kernel<G><<<(unsigned)blocks, kBlock, 0, stream>>>(n, c, logits, ldx, labels, ldl, mask, mask_mean,
+                                                                         row_stats, dlogits, ldd);
+}
+
 // g' = g + wd * p;  m += (1 - b1)(g' - m);  v += (1 - b2)(g'^2 - v);  p -= lr_t * m / (sqrt(v) + eps).
 // lr_t comes from device memory when lr_dev is set (a launch recorded in a HIP graph).
 __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -85,9 +156,22 @@ int gcn_softmax_xent_f32(int64_t n, int64_t c, const float* logits, int64_t ldx,
     if (!(mask_mean > 0.0f)) return fail(GCN_ERR_BAD_ARG, "mask_mean must be positive (an empty mask has no loss)");
     if (n == 0) return GCN_OK;
     if (!logits || !labels || !mask || !row_stats) return fail(GCN_ERR_BAD_ARG, "null pointer");
-    const int64_t blocks = std::min<int64_t>(ceil_div(n, kBlock), 1 << 16);
-    softmax_xent_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n, (int)c, logits, ldx, labels, ldl, mask,
-                                                                             mask_mean, row_stats, dlogits, ldd);
+    hipStream_t st = (hipStream_t)stream;
+#define GCN_XENT_GROUP(G) \
+    launch_xent_group<G>(n, (int)c, logits, ldx, labels, ldl, mask, mask_mean, row_stats, dlogits, ldd, st)
+    if (c <= 1) GCN_XENT_GROUP(1);
+    else if (c <= 2) GCN_XENT_GROUP(2);
+    else if (c <= 4) GCN_XENT_GROUP(4);
+    else if (c <= 8) GCN_XENT_GROUP(8);
+    else if (c <= 16) GCN_XENT_GROUP(16);
+    else if (c <= 32) GCN_XENT_GROUP(32);
+    else if (c <= 64) GCN_XENT_GROUP(64);
+    else {
+        const int64_t blocks = std::min<int64_t>(ceil_div(n, kBlock), 1 << 16);
+        softmax_xent_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(n, (int)c, logits, ldx, labels, ldl, mask, mask_mean,
+                                                                row_stats, dlogits, ldd);
+    }
+#undef GCN_XENT_GROUP
     GCN_LAUNCH_CHECK();
     return GCN_OK;
 }

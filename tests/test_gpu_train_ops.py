@@ -12,7 +12,7 @@ def _t(x):
     return torch.as_tensor(np.ascontiguousarray(x)).cuda()
 
 
-@pytest.mark.parametrize('n,c', [(2708, 7), (3327, 6), (19717, 3), (1, 1), (100003, 16), (513, 40)])
+@pytest.mark.parametrize('n,c', [(2708, 7), (3327, 6), (19717, 3), (1, 1), (100003, 16), (513, 40), (1000, 64), (777, 70)])
 def test_masked_cross_entropy_accuracy_and_gradient(oracle, n, c):
     from gcn_amd import sparse
     rng = np.random.default_rng(n + c)
@@ -42,6 +42,25 @@ def test_masked_cross_entropy_accuracy_and_gradient(oracle, n, c):
     stats2, none = sparse.softmax_xent(_t(logits), _t(labels), _t(mask), float(mask.astype(np.float32).mean()),
                                        want_grad=False)
     assert none is None and np.array_equal(stats2.cpu().numpy(), stats)
+
+
+@pytest.mark.parametrize('c', [3, 7, 16, 33, 70])
+def test_ties_go_to_the_first_class(c):
+    """argmax of equal logits (and of an all-zero label row) is class 0: such rows count as correct."""
+    import torch
+    from gcn_amd import sparse
+    n = 130
+    logits = torch.zeros((n, c), device='cuda')
+    logits[1::2, c // 2:] = 2.0                              # odd rows: the first maximum sits at c // 2
+    labels = torch.zeros((n, c), dtype=torch.int32, device='cuda')
+    labels[1::2, c // 2] = 1
+    mask = torch.ones(n, dtype=torch.int32, device='cuda')
+    stats, _ = sparse.softmax_xent(logits, labels, mask, 1.0)
+    assert bool((stats[:, 1] == 1.0).all())
+    labels[1::2] = 0
+    labels[1::2, c - 1] = 1                                  # now the label is the LAST of the tied maxima
+    stats, _ = sparse.softmax_xent(logits, labels, mask, 1.0)
+    assert bool((stats[1::2, 1] == 0.0).all()) and bool((stats[0::2, 1] == 1.0).all())
 
 
 def test_loss_kernel_rejects_an_empty_mask():
