@@ -105,7 +105,9 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
                                                            const float* __restrict__ a, int64_t lda,
                                                            const float* __restrict__ b, int64_t ldb,
                                                            float* __restrict__ c, int64_t ldc, int relu, int a_vec,
-                                                           int b_vec, int64_t tiles_m, int64_t tiles_n) {
+                                                           int b_vec, int64_t tiles_m, int64_t tiles_n,
+                                                           const float* __restrict__ gate, int64_t ldg,
+                                                           float divisor) {
     constexpr int kWavesN = (BN >= 64) ? 2 : 1;
     constexpr int kWavesM = 4 / kWavesN;
     constexpr int MT = kBM / (kWavesM * 32);
@@ -319,6 +321,48 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
         __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (gate) {
+        // C = gate > 0 ? (A.B) / divisor : 0 -- the backward of dropout(relu(.)) folded into the product
+        // that computes the gradient of its output (gate = that output: positive where the unit was
+        // active and kept)
+        if (interior) {
+            // the gate values of a 32x32 tile are all requested before the first store
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int64_t r0 = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);
+                    const int64_t c0 = n0 + (wn * NT + j) * 32 + l31;
+                    const float* gp = gate + r0 * ldg + c0;
+                    float gv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        gv[e] = gp[0];
+                        gp += ((e & 3) == 3) ? 5 * ldg : ldg;
+                    }
+                    float* cp = c + r0 * ldc + c0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        cp[0] = gv[e] > 0.0f ? __fdiv_rn(acc[i][j][e], divisor) : 0.0f;
+                        cp += ((e & 3) == 3) ? 5 * ldc : ldc;
+                    }
+                }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int64_t gc = n0 + (wn * NT + j) * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t gr = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (gr < m && gc < n)
+                        c[gr * ldc + gc] = gate[gr * ldg + gc] > 0.0f ? __fdiv_rn(acc[i][j][e], divisor) : 0.0f;
+                }
+            }
+        return;
+    }
     if (interior) {
         // no bounds tests and one running pointer per 32x32 tile: the guarded form below spends ~15
         // VALU instructions per stored element, as much issue time as a tenth of a K = 512 tile's MFMAs
@@ -356,7 +400,8 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n,
 
 template <int kBM, int BN>
 static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
-                       int trans_b, float* c, int64_t ldc, int relu, hipStream_t st) {
+                       int trans_b, float* c, int64_t ldc, int relu, hipStream_t st, const float* gate = nullptr,
+                       int64_t ldg = 0, float divisor = 1.0f) {
     const int64_t tiles_m = ceil_div(m, kBM), tiles_n = ceil_div(n, BN);
     const int64_t n_tiles = tiles_m * tiles_n;
     if (n_tiles > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
@@ -364,7 +409,7 @@ static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
     const int b_vec = (ldb % 4 == 0) && (((uintptr_t)b & 15) == 0);
 #define GCN_GEMM_GO(TB, BK)                                                                                  \
     gemm_mfma_kernel<kBM, BN, TB, BK><<<(unsigned)n_tiles, kBlock, 0, st>>>(m, n, k, a, lda, b, ldb, c, ldc, relu, a_vec, \
-                                                                       b_vec, tiles_m, tiles_n)
+                                                                       b_vec, tiles_m, tiles_n, gate, ldg, divisor)
     if (k <= 16) {
         if (trans_b)
             GCN_GEMM_GO(true, 16);
@@ -635,6 +680,21 @@ int gcn_gemm_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, c
     if (n <= 32) return launch_gemm<128, 32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
     if (n <= 64) return launch_gemm<128, 64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
     return launch_gemm<128, 128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
+}
+
+int gcn_gemm_gated_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                       int trans_b, const float* gate, int64_t ldg, float divisor, float* c, int64_t ldc,
+                       void* stream) {
+    if (m < 0 || n < 0 || k < 0) return fail(GCN_ERR_BAD_ARG, "negative dimension");
+    if (lda < k || ldc < n || ldg < n || ldb < (trans_b ? k : n))
+        return fail(GCN_ERR_BAD_ARG, "leading dimension too small");
+    if (!(divisor > 0.0f)) return fail(GCN_ERR_BAD_ARG, "divisor must be positive");
+    if (m == 0 || n == 0) return GCN_OK;
+    if (!c || !gate || (k > 0 && (!a || !b))) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 32) return launch_gemm<128, 32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, 0, st, gate, ldg, divisor);
+    if (n <= 64) return launch_gemm<128, 64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, 0, st, gate, ldg, divisor);
+    return launch_gemm<128, 128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, 0, st, gate, ldg, divisor);
 }
 
 int gcn_gemm_tn_workspace_bytes(int64_t m, int64_t n, int64_t k, size_t* bytes) {

@@ -156,6 +156,19 @@ struct DropArgs {
     uint64_t seed, stream_id;
 };
 
+// Dropout applied to the product's OUTPUT (the next layer's tf.nn.dropout on its input,
+// gcn/layers.py:185, fused into the store): element (r, col) of C draws decision
+// index_offset + r * pitch + col of stream `key` -- the decision a separate pass over a matrix
+// `pitch` columns wide would draw, of which C may be a row block and a column range.
+struct OutDrop {
+    uint64_t key;
+    float keep_prob;     // 1: off
+    int64_t index_offset;
+    int64_t pitch;
+    const uint64_t* stream_offset;  // as in DropArgs
+    uint64_t seed, stream_id;
+};
+
 // sparse_dropout decisions of one batch of U entries starting at kb, for a lane group of LPR lanes.
 // Every lane of a group needs all U decisions, but a decision costs a 64-bit hash: lane `sub` of the
 // group hashes only entries sub, sub + LPR, ... and a wave ballot hands the bits round.
@@ -322,7 +335,8 @@ __device__ __forceinline__ void accumulate_range_piped(int64_t k0, int64_t k1, c
 // out = act(acc + addend): the addend row (may be null) is the "+ X" of a smoothing step
 template <int VEC, int VPL>
 __device__ __forceinline__ void store_row(float* dst, const float* addend, const int (&col)[VPL],
-                                          const bool (&on)[VPL], float (&acc)[VPL][VEC], bool relu) {
+                                          const bool (&on)[VPL], float (&acc)[VPL][VEC], bool relu,
+                                          const OutDrop& od, int64_t row) {
 #pragma unroll
     for (int v = 0; v < VPL; ++v)
         if (on[v]) {
@@ -336,6 +350,12 @@ __device__ __forceinline__ void store_row(float* dst, const float* addend, const
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[v][e] = acc[v][e] > 0.0f ? acc[v][e] : 0.0f;
             }
+            if (od.keep_prob < 1.0f) {  // TF 1.x: div(x, keep_prob) * floor(keep_prob + uniform)
+                const uint64_t id = (uint64_t)(od.index_offset + row * od.pitch + col[v]);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    acc[v][e] = keep_entry(od.key, id + e, od.keep_prob) ? __fdiv_rn(acc[v][e], od.keep_prob) : 0.0f;
+            }
             store_vec<VEC>(dst + col[v], acc[v]);
         }
 }
@@ -347,7 +367,7 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                              uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
                                              const DropArgs& dr, int split, const float* __restrict__ add,
-                                             int64_t ldadd) {
+                                             int64_t ldadd, const OutDrop& od) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;  // columns covered per pass
     const int lane = threadIdx.x & 63;
@@ -381,7 +401,7 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
             else
                 accumulate_range<LPR, VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
             store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
-                                relu != 0);
+                                relu != 0, od, r);
         }
     }
 }
@@ -401,7 +421,7 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                                             const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                             uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
                                             const DropArgs& dr, int split, const float* __restrict__ add,
-                                            int64_t ldadd, int64_t nnz) {
+                                            int64_t ldadd, int64_t nnz, const OutDrop& od) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
@@ -549,7 +569,7 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
             if (k >= k1) {
                 if (r >= 0) {
                     store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
-                                        relu != 0);
+                                        relu != 0, od, r);
 #pragma unroll
                     for (int v = 0; v < VPL; ++v)
 #pragma unroll
@@ -614,7 +634,8 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
         accumulate_range<LPR, VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
-        store_row<VEC, VPL>(part + chunk * ldp, nullptr, col, on, acc, false);
+        const OutDrop none = {0, 1.0f, 0, 0, nullptr, 0, 0};   // partial rows are stored as they are
+        store_row<VEC, VPL>(part + chunk * ldp, nullptr, col, on, acc, false, none, 0);
     }
 }
 
@@ -638,18 +659,19 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
                                                            float* __restrict__ c, int64_t ldc,
                                                            float* __restrict__ part, int64_t ldp, int relu,
                                                            DropArgs dr, const float* __restrict__ add,
-                                                           int64_t ldadd) {
+                                                           int64_t ldadd, OutDrop od) {
     if (DROPOUT && dr.stream_offset) dr.key = stream_key(dr.seed, dr.stream_id + *dr.stream_offset);
+    if (od.keep_prob < 1.0f && od.stream_offset) od.key = stream_key(od.seed, od.stream_id + *od.stream_offset);
     const int64_t block = blockIdx.x;
     if (block < pv.chunk_blocks)
         chunks_block<LPR, VEC, VPL, DROPOUT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
                                              indices, vals, f, b, ldb, part, ldp, dr, pv.chunk_len);
     else if (LPR >= 32)
         strips_block<LPR, VEC, VPL, DROPOUT, (U > kUnroll)>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
-                                             vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd);
+                                             vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd, od);
     else
         slots_block<LPR, VEC, VPL, DROPOUT, U>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
-                                            vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd, pv.nnz);
+                                            vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd, pv.nnz, od);
 }
 
 // partial rows of each long row, added in chunk order; one wave per long row.  Partial rows are
@@ -660,7 +682,8 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(int64_t n_long
                                                                   const float* __restrict__ part, int64_t ldp,
                                                                   float* __restrict__ c, int64_t ldc, int relu,
                                                                   int vec_c, const float* __restrict__ add,
-                                                                  int64_t ldadd) {
+                                                                  int64_t ldadd, OutDrop od) {
+    if (od.keep_prob < 1.0f && od.stream_offset) od.key = stream_key(od.seed, od.stream_id + *od.stream_offset);
     constexpr int kDepth = 8;
     const int lane = threadIdx.x & 63;
     const int64_t li = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -696,6 +719,12 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(int64_t n_long
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.0f ? s[e] : 0.0f;
         }
+        if (od.keep_prob < 1.0f) {
+            const uint64_t id = (uint64_t)(od.index_offset + (int64_t)long_row[li] * od.pitch + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s[e] = keep_entry(od.key, id + e, od.keep_prob) ? __fdiv_rn(s[e], od.keep_prob) : 0.0f;
+        }
         if (vec_c) {
             store_vec<4>(dst + j, s);
         } else {
@@ -726,6 +755,7 @@ struct SpmmCall {
     DropArgs dr;
     const float* add;
     int64_t ldadd;
+    OutDrop od;
     hipStream_t st;
 };
 
@@ -752,14 +782,15 @@ static int launch_variant(const SpmmCall& a) {
     if (grid > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[0], a.st));
     spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U><<<(unsigned)grid, kBlock, 0, a.st>>>(
-        pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add, a.ldadd);
+        pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add, a.ldadd,
+        a.od);
     GCN_LAUNCH_CHECK();
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[1], a.st));
     if (lt.n_chunks > 0) {
         const unsigned grid2 = (unsigned)ceil_div(lt.n_long, kWaves);
         spmm_long_reduce_kernel<<<grid2, kBlock, 0, a.st>>>(lt.n_long, lt.long_row, lt.long_chunk, a.f, a.part,
                                                             a.ldp, a.c, a.ldc, a.relu, VEC == 4 ? 1 : 0, a.add,
-                                                            a.ldadd);
+                                                            a.ldadd, a.od);
         GCN_LAUNCH_CHECK();
     }
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[2], a.st));
@@ -799,7 +830,7 @@ template <bool DROPOUT>
 static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
                       int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
                       size_t workspace_bytes, DropArgs dr, void* stream, const float* add = nullptr,
-                      int64_t ldadd = 0) {
+                      int64_t ldadd = 0, const OutDrop* od = nullptr) {
     if (!plan) return fail(GCN_ERR_BAD_ARG, "plan is null");
     if (add && ldadd < f) return fail(GCN_ERR_BAD_ARG, "bad addend leading dimension %lld", (long long)ldadd);
     if (f < 0 || ldb < f || ldc < f || ldb > INT32_MAX || f > INT32_MAX - 1024)
@@ -825,6 +856,7 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
     a.dr = dr;
     a.add = add;
     a.ldadd = ldadd;
+    a.od = od ? *od : OutDrop{0, 1.0f, 0, 0, nullptr, 0, 0};
     a.st = (hipStream_t)stream;
     const int64_t max_chunks = std::max(plan->table[0].n_chunks, plan->table[1].n_chunks);
     if (max_chunks > 0) {
@@ -1041,6 +1073,21 @@ int gcn_spmm_csr_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, c
     DropArgs dr = {perm, stream_key(seed, stream_id), keep_prob, 1.0f / keep_prob, stream_offset, seed, stream_id};
     return spmm_entry<true>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
                             stream);
+}
+
+int gcn_spmm_csr_out_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                                 const float* vals, int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc,
+                                 int flags, float keep_prob, uint64_t seed, uint64_t stream_id,
+                                 const uint64_t* stream_offset, int64_t index_offset, int64_t pitch, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
+    if (index_offset < 0 || pitch < f)
+        return fail(GCN_ERR_BAD_ARG, "bad decision layout: index_offset=%lld pitch=%lld for %lld columns",
+                    (long long)index_offset, (long long)pitch, (long long)f);
+    DropArgs dr = {nullptr, 0, 1.0f, 1.0f};
+    OutDrop od = {stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset, seed, stream_id};
+    return spmm_entry<false>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
+                             stream, nullptr, 0, &od);
 }
 
 }  // extern "C"

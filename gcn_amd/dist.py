@@ -291,13 +291,21 @@ def column_shares(f, shares):
     return [(lo, hi) for lo, hi in zip(edges, edges[1:]) if hi > lo]
 
 
-def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None):
-    """out = A_local . B with the exchange of column range i+1 in flight during the product of range i."""
+def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None, out_dropout=None):
+    """out = A_local . B with the exchange of column range i+1 in flight during the product of range i.
+    ``out_dropout`` (sparse.OutDropout over the full width, index_offset = first local row * width):
+    the output is stored already dropped."""
     spmm = spmm or sparse.spmm
     f = b_local.shape[1]
     ranges = ranges or [(0, f)]
+    extra = {}
+    if out_dropout is not None:
+        out_dropout = sparse.OutDropout(out_dropout.keep_prob, out_dropout.seed, out_dropout.stream_id,
+                                        out_dropout.index_offset, f)
     if len(ranges) == 1:
-        return spmm(plan.compact, plan.exchange(b_local), relu=relu, out=out)
+        if out_dropout is not None:
+            extra['out_dropout'] = out_dropout
+        return spmm(plan.compact, plan.exchange(b_local), relu=relu, out=out, **extra)
     c0, c1 = ranges[0]
     pending = plan.exchange(b_local[:, c0:c1], slot=0, async_op=True)
     for i, (c0, c1) in enumerate(ranges):
@@ -306,5 +314,7 @@ def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None):
             n0, n1 = ranges[i + 1]
             pending = plan.exchange(b_local[:, n0:n1], slot=(i + 1) & 1, async_op=True)
         work.wait()
-        spmm(plan.compact, rows, relu=relu, out=out[:, c0:c1], wide_split=f >= 128)
+        if out_dropout is not None:
+            extra['out_dropout'] = out_dropout.columns(c0)
+        spmm(plan.compact, rows, relu=relu, out=out[:, c0:c1], wide_split=f >= 128, **extra)
     return out

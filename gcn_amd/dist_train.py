@@ -16,7 +16,7 @@ from .layers import _GemmFn
 from .models import TfAdam
 
 
-def _product(plan, b_local, relu, chunks):
+def _product(plan, b_local, relu, chunks, out_dropout=None):
     """A_local . exchange(B) into a fresh tensor; wide operands pipeline the exchange over column ranges."""
     out = torch.empty((plan.compact.n_rows, b_local.shape[1]), dtype=torch.float32, device=b_local.device)
     f = b_local.shape[1]
@@ -26,15 +26,16 @@ def _product(plan, b_local, relu, chunks):
         ranges = column_shares(f, chunks)
     else:
         ranges = column_chunks(f, chunks)
-    return halo_product(plan, b_local, out, relu, ranges)
+    return halo_product(plan, b_local, out, relu, ranges, out_dropout=out_dropout)
 
 
 class _HaloSpmmFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, b_local, fuse_relu, chunks, gate_here):
-        """``gate_here`` False: the ReLU's backward gate is applied by the dropout that consumes this
-        output (one pass over the activations instead of two)."""
-        out = _product(plan, b_local, fuse_relu, chunks)
+    def forward(ctx, plan, b_local, fuse_relu, chunks, gate_here, out_dropout=None):
+        """``gate_here`` False: the backward of the ReLU (and of ``out_dropout``, the next layer's input
+        dropout applied in this product's store) is applied by whoever consumes this output -- the
+        gradient that arrives here is already the one of the pre-activation."""
+        out = _product(plan, b_local, fuse_relu, chunks, out_dropout)
         ctx.plan, ctx.gate, ctx.chunks = plan, fuse_relu and gate_here, chunks
         if ctx.gate:
             ctx.save_for_backward(out)
@@ -47,26 +48,40 @@ class _HaloSpmmFn(torch.autograd.Function):
             grad = sparse.dropout(grad, 1.0, 0, 0, gate=out)
         plan = ctx.plan
         # symmetric support: rows of A^T are rows of A
-        return None, _product(plan, grad.contiguous(), False, ctx.chunks), None, None, None
+        return None, _product(plan, grad.contiguous(), False, ctx.chunks), None, None, None, None
+
+
+class _GatedGemmFn(torch.autograd.Function):
+    """h_dropped . W where h_dropped = dropout(relu(z)) came out of a product's store.  The gradient it
+    returns for its left operand is the gradient of z: (dP . W^T) / keep where h_dropped > 0, else 0 --
+    the dropout's and the ReLU's backward in the store of the product dP . W^T (h_dropped is positive
+    exactly where the unit was active and kept), instead of a pass over the activations."""
+
+    @staticmethod
+    def forward(ctx, h_dropped, w, keep_prob):
+        ctx.save_for_backward(h_dropped, w)
+        ctx.keep_prob = keep_prob
+        return sparse.gemm(h_dropped, w)
+
+    @staticmethod
+    def backward(ctx, grad):
+        h, w = ctx.saved_tensors
+        grad = grad.contiguous()
+        d_h = sparse.gemm_gated(grad, w, h, ctx.keep_prob, trans_b=True) if ctx.needs_input_grad[0] else None
+        d_w = sparse.gemm_tn(h, grad) if ctx.needs_input_grad[1] else None
+        return d_h, d_w, None
 
 
 class _ShardDropoutFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, keep_prob, seed, stream_id, index_offset, relu_input):
-        """``relu_input``: x is the output of a ReLU whose backward gate (x > 0) is folded into this
-        function's backward pass."""
+    def forward(ctx, x, keep_prob, seed, stream_id, index_offset):
         ctx.args = (keep_prob, seed, stream_id, index_offset)
-        ctx.relu_input = relu_input
-        if relu_input:
-            ctx.save_for_backward(x)
         return sparse.dropout(x, keep_prob, seed, stream_id, index_offset=index_offset)
 
     @staticmethod
     def backward(ctx, grad):
         keep_prob, seed, stream_id, index_offset = ctx.args
-        gate = ctx.saved_tensors[0] if ctx.relu_input else None
-        return (sparse.dropout(grad, keep_prob, seed, stream_id, gate=gate, index_offset=index_offset),
-                None, None, None, None, None)
+        return sparse.dropout(grad, keep_prob, seed, stream_id, index_offset=index_offset), None, None, None, None
 
 
 class ShardedGCN(object):
@@ -98,16 +113,23 @@ class ShardedGCN(object):
         return t
 
     def forward(self, x_local, train):
+        """Dropout on every layer's input (gcn/models.py:60): a pass over the features for the first
+        layer; for the others it is applied in the store of the product that makes the input, and its
+        backward (with the ReLU's) in the store of the product that makes the input's gradient."""
         keep = 1.0 - self.dropout if train else 1.0
+        drop = keep < 1.0
         h = x_local
         last = len(self.weights) - 1
         for li, w in enumerate(self.weights):
-            if keep < 1.0:
+            if drop and li == 0:
                 offset = self.shard.row_begin * h.shape[1]
-                h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64 + li, offset, li > 0)
-            p = _GemmFn.apply(h, w)
-            # the next layer's dropout (if any) applies this layer's ReLU gate in its backward
-            h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not (keep < 1.0))
+                h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64, offset)
+            p = _GatedGemmFn.apply(h, w, keep) if drop and li > 0 else _GemmFn.apply(h, w)
+            next_drop = None
+            if drop and li != last:
+                next_drop = sparse.OutDropout(keep, self.seed, self.step_count * 64 + li + 1,
+                                              self.shard.row_begin * w.shape[1])
+            h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop)
         return h
 
     def _local_mask_mean(self, mask_local):

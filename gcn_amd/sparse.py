@@ -297,10 +297,26 @@ def _check_out(out, n_rows, f):
         raise ValueError('out must be a row-major float32 [%d x %d] view' % (n_rows, f))
 
 
-def spmm(a, b, relu=False, out=None, wide_split=False):
+class OutDropout(object):
+    """Dropout of a product's OUTPUT, applied in its store (the next layer's tf.nn.dropout on its input,
+    gcn/layers.py:185).  Element (r, c) of the output draws decision ``index_offset + r * pitch + c`` of
+    stream (seed, stream_id): the one ``dropout`` draws for a matrix ``pitch`` columns wide of which
+    the output is a row block (index_offset = first row * pitch) and possibly a column range."""
+
+    def __init__(self, keep_prob, seed, stream_id, index_offset=0, pitch=None):
+        self.keep_prob, self.seed, self.stream_id = float(keep_prob), int(seed), int(stream_id)
+        self.index_offset, self.pitch = int(index_offset), pitch
+
+    def columns(self, c0):
+        """The same decisions for the column range that starts at column ``c0``."""
+        return OutDropout(self.keep_prob, self.seed, self.stream_id, self.index_offset + c0, self.pitch)
+
+
+def spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None):
     """``a @ b`` for a DeviceCSR ``a`` and dense float32 ``b`` (optionally with ReLU fused).
     ``wide_split`` cuts long rows as a wide product does, whatever the width of ``b``: use it when
-    ``b`` is a range of the columns of a wider operand and the bits must match the full product."""
+    ``b`` is a range of the columns of a wider operand and the bits must match the full product.
+    ``out_dropout`` (an OutDropout): the result is written already dropped, after the ReLU."""
     _require_cuda(b)
     b = _rowmajor(b)
     if b.shape[0] != a.n_cols:
@@ -311,9 +327,15 @@ def spmm(a, b, relu=False, out=None, wide_split=False):
     else:
         _check_out(out, a.n_rows, f)
     ws, ws_bytes = a.plan.workspace(f, b.device)
+    flags = (_lib.GCN_RELU if relu else 0) | (_lib.GCN_SPLIT_WIDE if wide_split else 0)
+    if out_dropout is not None and out_dropout.keep_prob < 1.0:
+        d = out_dropout
+        _lib.call('gcn_spmm_csr_out_dropout_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(b),
+                  _ld(b), _p(out), _ld(out), flags, d.keep_prob, d.seed, d.stream_id, _p(_stream_offset),
+                  d.index_offset, f if d.pitch is None else int(d.pitch), _p(ws), ws_bytes, _stream())
+        return out
     _lib.call('gcn_spmm_csr_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(b), _ld(b),
-              _p(out), _ld(out), (_lib.GCN_RELU if relu else 0) | (_lib.GCN_SPLIT_WIDE if wide_split else 0), _p(ws),
-              ws_bytes, _stream())
+              _p(out), _ld(out), flags, _p(ws), ws_bytes, _stream())
     return out
 
 
@@ -414,6 +436,26 @@ def gemm(a, b, trans_b=False, relu=False, out=None):
         c = out
     _lib.call('gcn_gemm_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), 1 if trans_b else 0, _p(c), _ld(c),
               _lib.GCN_RELU if relu else 0, _stream())
+    return c
+
+
+def gemm_gated(a, b, gate, divisor, trans_b=False, out=None):
+    """``where(gate > 0, (a @ b) / divisor, 0)``: the gradient of a product's left operand with the
+    backward of the dropout(relu(.)) that made that operand folded into the store (``gate`` is the
+    dropped activation matrix itself, ``divisor`` the keep probability)."""
+    _require_cuda(a, b, gate)
+    a, b, gate = _rowmajor(a), _rowmajor(b), _rowmajor(gate)
+    m, k = a.shape
+    n = b.shape[0] if trans_b else b.shape[1]
+    if (b.shape[1] if trans_b else b.shape[0]) != k or tuple(gate.shape) != (m, n):
+        raise ValueError('shape mismatch in gemm_gated')
+    if out is None:
+        c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    else:
+        _check_out(out, m, n)
+        c = out
+    _lib.call('gcn_gemm_gated_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), 1 if trans_b else 0, _p(gate), _ld(gate),
+              float(divisor), _p(c), _ld(c), _stream())
     return c
 
 

@@ -176,6 +176,20 @@ int gcn_spmm_csr_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, c
                              int64_t ldc, int flags, float keep_prob, uint64_t seed, uint64_t stream_id,
                              const uint64_t* stream_offset, void* workspace, size_t workspace_bytes, void* stream);
 
+/* C = dropout(act(A . B)): the product of one layer (gcn/layers.py:202-208) with the NEXT layer's
+ * tf.nn.dropout on its input (gcn/layers.py:185, reached through gcn/models.py:56-66) applied in the
+ * store, so the activations are written once, already dropped.  Element (r, c) draws the decision
+ * of id index_offset + r * pitch + c in stream (seed, stream_id): what gcn_dropout_f32 draws for a
+ * matrix `pitch` columns wide.  C may be a row block of that matrix (index_offset = first row *
+ * pitch) and a column range of it (index_offset += first column; pitch >= f).  The dropped output
+ * is also the gate of the backward pass: it is positive exactly where the unit was active and
+ * kept (see gcn_gemm_gated_f32).  stream_offset: as for gcn_spmm_csr_dropout_f32. */
+int gcn_spmm_csr_out_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                                 const float* vals, int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc,
+                                 int flags, float keep_prob, uint64_t seed, uint64_t stream_id,
+                                 const uint64_t* stream_offset, int64_t index_offset, int64_t pitch, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Dense pieces of the layer.                                                 *
  * ------------------------------------------------------------------------- */
@@ -201,6 +215,15 @@ int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, cons
  * trans_b = 1: B is stored [n x k] (dH = dP . W^T in the backward pass). */
 int gcn_gemm_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
                  int trans_b, float* c, int64_t ldc, int flags, void* stream);
+
+/* C = gate > 0 ? (A . op(B)) / divisor : 0.  The gradient of tf.matmul w.r.t. its left operand
+ * (dH = dP . W^T, gcn/layers.py:32-33 under gcn/models.py:86) with the backward of the
+ * dropout(relu(.)) that produced that operand folded into the store: gate is the dropped
+ * activation matrix [m x n] itself and divisor the keep probability.  Same bits as gcn_gemm_f32
+ * followed by gcn_dropout_f32 with the ReLU gate. */
+int gcn_gemm_gated_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                       int trans_b, const float* gate, int64_t ldg, float divisor, float* c, int64_t ldc,
+                       void* stream);
 
 /* C[k x n] = A^T . G for A [m x k] and G [m x n], both row-major: the weight gradient
  * dW = H^T . dP that tf.train.AdamOptimizer.minimize derives for tf.matmul and for

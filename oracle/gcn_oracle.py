@@ -343,11 +343,12 @@ def sparse_dropout_values(vals, keep_prob, key):
     return keep, vals * inv
 
 
-def dense_dropout(x, keep_prob, key):
+def dense_dropout(x, keep_prob, key, index_offset=0):
     """tf.nn.dropout(x, keep_prob) as called at gcn/layers.py:185 (TF 1.x:
-    ``div(x, keep_prob) * floor(keep_prob + uniform)``)."""
+    ``div(x, keep_prob) * floor(keep_prob + uniform)``).  ``index_offset``: x is a row block of a taller
+    matrix and draws that matrix's decisions (first row * width)."""
     x = np.asarray(x, dtype=np.float32)
-    keep = keep_mask(key, np.arange(x.size), keep_prob).reshape(x.shape)
+    keep = keep_mask(key, np.arange(x.size) + index_offset, keep_prob).reshape(x.shape)
     return (x / np.float32(keep_prob)) * keep.astype(np.float32), keep
 
 

@@ -121,3 +121,26 @@ def test_gather_rows_of_a_column_range():
         assert bool((out[:, c1 - c0:] == -1.0).all())
     empty = torch.empty((0, 72), device='cuda')
     sparse.gather_rows(src, rows[:0], empty)
+
+
+@pytest.mark.parametrize('m,n,k', [(5000, 256, 16), (1000, 130, 33), (129, 33, 2), (4096, 16, 256), (1, 1, 1)])
+@pytest.mark.parametrize('trans_b', [False, True])
+def test_gated_product_equals_product_then_gate(oracle, m, n, k, trans_b):
+    """where(gate > 0, (A . B) / keep, 0) in the product's store: the bits of the product followed by the
+    dropout / ReLU backward pass over it."""
+    import torch
+    from gcn_amd import sparse
+    a = _t(oracle.synthetic_dense(m, k, seed=71))
+    b = oracle.synthetic_dense(k, n, seed=72)
+    bt = _t(np.ascontiguousarray(b.T)) if trans_b else _t(b)
+    gate = _t(oracle.synthetic_dense(m, n, seed=73))
+    gate = torch.where(gate > 0.3, gate, torch.zeros_like(gate))      # zeros and positives, as a dropped ReLU output
+    plain = sparse.gemm(a, bt, trans_b=trans_b)
+    for keep in (0.5, 0.8):
+        got = sparse.gemm_gated(a, bt, gate, keep, trans_b=trans_b)
+        want = torch.where(gate > 0, plain / torch.full_like(plain, keep), torch.zeros_like(plain))   # IEEE division
+        assert torch.equal(got, want)
+    wide = torch.full((m, n + 4), 2.0, device='cuda')
+    sparse.gemm_gated(a, bt, gate, 0.5, trans_b=trans_b, out=wide[:, 2:2 + n])
+    assert torch.equal(wide[:, 2:2 + n], torch.where(gate > 0, plain / torch.full_like(plain, 0.5), torch.zeros_like(plain)))
+    assert bool((wide[:, :2] == 2.0).all()) and bool((wide[:, 2 + n:] == 2.0).all())

@@ -212,3 +212,33 @@ def test_sparse_dropout_product_bit_exact(dataset_fx, oracle, keep_prob):
     assert np.array_equal(out_t[short], ref_t[short])
     ref_t64 = oracle.spmm_csr_f64(np.cumsum(tp2), ti[kt], tv[kt], g)
     assert np.abs(out_t - ref_t64).max() <= REL_TOL * np.abs(ref_t64).max()
+
+
+@pytest.mark.parametrize('f', [16, 256, 36, 5, 512])
+@pytest.mark.parametrize('keep_prob', [0.5, 0.8])
+def test_dropout_in_the_store_equals_the_separate_pass(oracle, f, keep_prob):
+    """dropout(relu(A . B)) written by the product itself (the next layer's tf.nn.dropout,
+    gcn/layers.py:185): the bits of the product followed by the oracle's dense dropout, for short rows,
+    chunked hub rows, the element path (f = 5), a row block and a column range of a wider matrix."""
+    import torch
+    from gcn_amd import sparse
+    rng = np.random.RandomState(4)
+    n = 3000
+    ip, ix = _skewed_graph(rng, n, {3, 1500}, hub_deg=2500, base_deg=6)
+    v = rng.uniform(-1, 1, ix.size).astype(np.float32)
+    a = _device_csr(n, n, ip, ix, v)
+    b = _t(oracle.synthetic_dense(n, f, seed=10))
+    plain = sparse.spmm(a, b, relu=True)
+    row0 = 777                                              # this matrix is rows 777.. of a taller one
+    od = sparse.OutDropout(keep_prob, 21, 5, index_offset=row0 * f)
+    fused = sparse.spmm(a, b, relu=True, out_dropout=od)
+    ref, _ = oracle.dense_dropout(plain.cpu().numpy(), keep_prob, oracle.stream_key(21, 5), index_offset=row0 * f)
+    assert np.array_equal(fused.cpu().numpy(), ref)
+    assert torch.equal(fused, sparse.dropout(plain, keep_prob, 21, 5, index_offset=row0 * f))
+    assert torch.equal(fused > 0, (plain > 0) & (fused != 0))      # the dropped output is its own backward gate
+    if f >= 16:                                             # a column range of the same output
+        c0, c1 = 4, 4 + 8
+        part = torch.full((n, 8), -3.0, device='cuda')
+        sparse.spmm(a, b[:, c0:c1], relu=True, out=part, wide_split=f >= 128,
+                    out_dropout=sparse.OutDropout(keep_prob, 21, 5, index_offset=row0 * f, pitch=f).columns(c0))
+        assert torch.equal(part, fused[:, c0:c1])
