@@ -8,8 +8,9 @@
 One step = one pass of the product over the whole graph with inputs resident in HBM.
 Default workload: R-MAT scale 24 (2^24 nodes), edge factor 16 (average degree ~32 after
 symmetrisation), 256-wide float32 features, A_hat = D^-1/2 (A+I) D^-1/2.  With N > 1 the rows
-of A_hat, B and C are split in N contiguous blocks; every step all-gathers B over RCCL and then
-multiplies locally (strong scaling: the graph does not grow with N).
+of A_hat, B and C are split in N contiguous blocks; every step each rank receives the rows of B its
+block references (RCCL all-to-all, pipelined over ranges of feature columns) and multiplies locally
+(strong scaling: the graph does not grow with N).
 
 Prints ONE JSON line on rank 0.
 """
@@ -17,6 +18,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -26,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak, GB/s
+EPOCH_LIMIT_S = 300           # the training-step leg gives up after this long (the product's line is printed regardless)
 
 
 def parse_args():
@@ -312,7 +315,20 @@ def main():
     ranges_used = list(op.ranges) if (world > 1 and not args.allgather) else None
     # GCN epoch on the same graph, every rank takes part
     epoch = None
+    printed = threading.Lock()
+    watchdog = None
     if not args.no_epoch:
+        # A rank that fails alone inside the training step leaves the others waiting in a collective:
+        # the product's line must still come out, so a timer thread prints it and ends the process.
+        def give_up():
+            if printed.acquire(False):
+                if rank == 0:
+                    line['gcn_epoch_rmat'] = {'error': 'no result within %d s' % EPOCH_LIMIT_S}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        watchdog = threading.Timer(EPOCH_LIMIT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         a.plan.set_timing(False)
         if world == 1:
             del c
@@ -326,6 +342,10 @@ def main():
             epoch = rmat_epoch_ms(shard, b_local, world, chunks=shares)
         except Exception as exc:            # the product's line above stays valid whatever happens here
             epoch = {'error': '%s: %s' % (type(exc).__name__, exc)}
+    if watchdog is not None:
+        watchdog.cancel()
+    if not printed.acquire(False):
+        time.sleep(60)                      # the timer thread is printing and ends the process
     if rank == 0:
         if epoch is not None:
             line['gcn_epoch_rmat'] = epoch
