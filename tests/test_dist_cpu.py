@@ -27,9 +27,15 @@ class _HostCSR(object):
         return int(self.indices.numel())
 
 
-def _oracle_spmm(a, b, relu=False, out=None, wide_split=False):
+def _oracle_spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None):
     import gcn_oracle
     c = gcn_oracle.spmm_csr(a.indptr.numpy(), a.indices.numpy(), a.values.numpy(), b.numpy(), relu=relu)
+    if out_dropout is not None:                 # decision ids as the HIP store computes them
+        d = out_dropout
+        pitch = c.shape[1] if d.pitch is None else d.pitch
+        ids = d.index_offset + np.arange(c.shape[0])[:, None] * pitch + np.arange(c.shape[1])[None, :]
+        keep = gcn_oracle.keep_mask(gcn_oracle.stream_key(d.seed, d.stream_id), ids, d.keep_prob)
+        c = (c / np.float32(d.keep_prob)) * keep.astype(np.float32)
     out.copy_(torch.from_numpy(c))
     return out
 
@@ -72,6 +78,14 @@ def _worker(rank, world, port, result_dir):
         piped = gdist.HaloSpmm(shard, f, spmm=_oracle_spmm, plan=halo.plan, chunks=3)
         assert piped.ranges == [(0, 4), (4, 8), (8, 16)]
         assert torch.equal(piped(torch.from_numpy(b[r0:r1].copy()), relu=True), c_local)
+        # dropout in the product's store: a rank draws its row block's decisions of the unsplit matrix,
+        # whole or range by range
+        drop = sparse.OutDropout(0.5, 11, 3, index_offset=r0 * f)
+        want, _ = gcn_oracle.dense_dropout(c_local.numpy(), 0.5, gcn_oracle.stream_key(11, 3), index_offset=r0 * f)
+        for ranges in ([(0, f)], [(0, 4), (4, 8), (8, 16)]):
+            got = gdist.halo_product(halo.plan, torch.from_numpy(b[r0:r1].copy()), torch.empty_like(c_local), True,
+                                     ranges, _oracle_spmm, out_dropout=drop)
+            assert np.array_equal(got.numpy(), want)
         # the pipeline is picked by measurement; a rigged clock makes the choice predictable, the
         # MAX over ranks makes it the same everywhere, and the result does not change
         ticks = iter(range(1000))
