@@ -9,6 +9,7 @@
 namespace gcn {
 
 constexpr int kBlock = 256;
+constexpr int kXentTile = 32;   // wave-sized row groups per block of the loss kernel
 
 // row_stats[i] = (CE_i * w_i, correct_i * w_i) with w_i = mask_i / mean(mask);
 // dlogits[i][c] = d(mean_i CE_i w_i) / d logits[i][c] = (softmax_ic * sum_c labels_ic - labels_ic) * w_i / n.
@@ -27,10 +28,12 @@ __global__ void softmax_xent_group_kernel(int64_t n, int c, const float* __restr
     const float inv_n = 1.0f / (float)n;
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    // a block walks a contiguous stretch of kXentTile wave-sized row groups, its waves interleaved:
+    // consecutive blocks read consecutive memory
     const int64_t n_groups = (n + kRows - 1) / kRows;
-    for (int64_t g = wave; g < n_groups; g += n_waves) {    // uniform per wave: every lane takes part in the shuffles
+    const int64_t g_begin = (int64_t)blockIdx.x * kXentTile;
+    const int64_t g_end = g_begin + kXentTile < n_groups ? g_begin + kXentTile : n_groups;
+    for (int64_t g = g_begin + (threadIdx.x >> 6); g < g_end; g += kBlock / 64) {   // uniform per wave: every lane takes part in the shuffles
         const int64_t i = g * kRows + lane / G;
         const bool live = i < n && sub < c;
         float x = live ? logits[i * ldx + sub] : -INFINITY;
@@ -120,7 +123,7 @@ static void launch_xent_group(int64_t n, int c, const float* logits, int64_t ldx
                               const int32_t* mask, float mask_mean, float* row_stats, float* dlogits, int64_t ldd,
                               hipStream_t stream) {
     const int64_t n_groups = ceil_div(n, (int64_t)(64 / G));
-    const int64_t blocks = std::min<int64_t>(ceil_div(n_groups, (int64_t)(kBlock / 64)), 1 << 16);
+    const int64_t blocks = ceil_div(n_groups, (int64_t)kXentTile);
     softmax_xent_group_kernel<G><<<(unsigned)blocks, kBlock, 0, stream>>>(n, c, logits, ldx, labels, ldl, mask, mask_mean,
                                                                          row_stats, dlogits, ldd);
 }
@@ -155,6 +158,7 @@ int gcn_softmax_xent_f32(int64_t n, int64_t c, const float* logits, int64_t ldx,
         return fail(GCN_ERR_BAD_ARG, "bad shape: n=%lld c=%lld", (long long)n, (long long)c);
     if (!(mask_mean > 0.0f)) return fail(GCN_ERR_BAD_ARG, "mask_mean must be positive (an empty mask has no loss)");
     if (n == 0) return GCN_OK;
+    if (n > ((int64_t)1 << 35)) return fail(GCN_ERR_BAD_ARG, "more than 2^35 rows in one launch");
     if (!logits || !labels || !mask || !row_stats) return fail(GCN_ERR_BAD_ARG, "null pointer");
     hipStream_t st = (hipStream_t)stream;
 #define GCN_XENT_GROUP(G) \
