@@ -99,10 +99,12 @@ __global__ void gather_rows_kernel(int64_t n_out, int64_t f, const float* __rest
 
 // ------------------------------------------------------------------------------------------------
 // C[m x n] = A[m x k] . op(B) with v_mfma_f32_32x32x2_f32 (exact float32 products and sums).
-// Block tile 128 x BN (BN = 32, 64, 128), 4 waves, K staged 32 deep through one LDS buffer; 35 KB of
-// LDS and ~110 VGPRs let 4 blocks share a CU, and it is the other blocks that cover a block's
-// barriers and its global-load latency (a second LDS buffer at half the occupancy measured the same
-// or slower, a 256 x 128 tile at 2 blocks per CU 15 % slower).  The loads of tile t+1 go to registers before the MFMAs of tile t and to LDS after them.
+// Block tile 128 x BN (BN = 32, 64, 128), 4 waves, K staged 32 deep through one LDS buffer (35 KB).
+// The kernel is bounded to 168 registers (64 of them the accumulators) so that 3 blocks share a CU:
+// it is the other blocks that cover a block's barriers and its global-load latency (at 2 blocks per
+// CU: 124 instead of 130 TFLOP/s on 2^22 x 512 x 512; the few spills this costs sit outside the k
+// loop; 4 blocks would need 128 registers and spill inside it).  A second LDS buffer at lower
+// occupancy measured the same or slower, 256 x 128 and 128 x 256 tiles 15 % slower.  The loads of tile t+1 go to registers before the MFMAs of tile t and to LDS after them.
 //  - A sits row-major in LDS as it does in memory (pitch 36 floats: conflict-free 128-bit reads and
 //    writes).  The MFMA wants, per lane, A[row = lane % 32][k = 2 s + lane / 32] at step s; instead
 //    lanes 0-31 take k = 0..15 of the stage and lanes 32-63 k = 16..31, so a lane reads 4
@@ -120,7 +122,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // kBK = 32, or 16 for products whose whole K fits 16 (hidden -> classes)
 template <int kBM, int BN, bool TRANS_B, int kBK>
-__global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(int64_t m, int64_t n, int64_t k,
+__global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t n, int64_t k,
                                                            const float* __restrict__ a, int64_t lda,
                                                            const float* __restrict__ b, int64_t ldb,
                                                            float* __restrict__ c, int64_t ldc, int relu, int a_vec,
