@@ -457,7 +457,7 @@ static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
 // and reduce_splits_kernel adds them in range order, so the result does not depend on scheduling.
 // ------------------------------------------------------------------------------------------------
 template <int TM, int BN>
-__global__ __launch_bounds__(64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)))
+__global__ __launch_bounds__(64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)), 3)
 void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a, int64_t lda,
                     const float* __restrict__ g, int64_t ldg, float* __restrict__ out, int64_t ldo,
                     int64_t split_stride, int64_t rows_per_split, int vec_ok, int64_t tiles_n) {
