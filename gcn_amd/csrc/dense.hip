@@ -104,7 +104,9 @@ __global__ void gather_rows_kernel(int64_t n_out, int64_t f, const float* __rest
 // it is the other blocks that cover a block's barriers and its global-load latency (at 2 blocks per
 // CU: 124 instead of 130 TFLOP/s on 2^22 x 512 x 512; the few spills this costs sit outside the k
 // loop; 4 blocks would need 128 registers and spill inside it).  A second LDS buffer at lower
-// occupancy measured the same or slower, 256 x 128 and 128 x 256 tiles 15 % slower.  The loads of tile t+1 go to registers before the MFMAs of tile t and to LDS after them.
+// occupancy measured the same or slower, 256 x 128 and 128 x 256 tiles 15 % slower, 128 x 64 tiles at 4
+// blocks per CU 2 % slower, and persistent blocks that run the k stages of successive tiles as one
+// pipeline 3-6 % slower (the hardware's block dispatch balances better than a static tile list).  The loads of tile t+1 go to registers before the MFMAs of tile t and to LDS after them.
 //  - A sits row-major in LDS as it does in memory (pitch 36 floats: conflict-free 128-bit reads and
 //    writes).  The MFMA wants, per lane, A[row = lane % 32][k = 2 s + lane / 32] at step s; instead
 //    lanes 0-31 take k = 0..15 of the stage and lanes 32-63 k = 16..31, so a lane reads 4

@@ -34,7 +34,8 @@ def test_dense_dropout_bit_exact(oracle, keep_prob, shape):
 
 @pytest.mark.parametrize('m,n,k', [(2708, 7, 16), (3327, 6, 16), (19717, 3, 16), (1000, 16, 1433), (513, 130, 257),
                                    (4096, 512, 512), (1, 1, 1), (129, 33, 2), (300, 200, 17), (257, 64, 31),
-                                   (256, 256, 64), (384, 96, 48)])
+                                   (256, 256, 64), (384, 96, 48),
+                                   (25600, 512, 96), (128 * 300, 384, 32)])      # whole tiles, many of them
 @pytest.mark.parametrize('trans_b', [False, True])
 def test_gemm_mfma_against_float64(oracle, m, n, k, trans_b):
     from gcn_amd import sparse
