@@ -48,6 +48,7 @@ SIGNATURES = {
     'gcn_rmat_csr': [_int, _int, _u64, _int, _vp, _vp, _vp, _vp, _sz, _vp],
     'gcn_fill_synthetic_f32': [_i64, _u64, _vp, _vp],
     'gcn_spmm_plan_create': [_i64, _i64, _i64, _vp, ctypes.POINTER(_vp), _vp],
+    'gcn_spmm_plan_create_split': [_i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_vp), _vp],
     'gcn_spmm_plan_destroy': [_vp],
     'gcn_spmm_plan_info': [_vp, _pi64],
     'gcn_spmm_plan_workspace_bytes': [_vp, _i64, _psz],

@@ -26,6 +26,7 @@ struct gcn_spmm_plan {
     int64_t n_strips;
     int strip_nnz;       // entries per strip
     int chunk_len;       // entries per chunk of a long row; 0: the split threshold itself
+    int split[2];        // rows longer than this are summed chunk-wise (narrow / wide dense operands)
     int device;
     int32_t* strip_row;  // [n_strips + 1] first row starting in each strip
     // rows longer than the split threshold, cut in chunks of that many entries; table 0 serves narrow
@@ -58,7 +59,6 @@ static inline int strip_nnz_for(int64_t work) {
 }
 constexpr int kSplitNarrow = 256;   // lane groups narrower than a wave: every work item <= 256 entries
 constexpr int kSplitWide = 1024;    // one wave per row
-static inline int split_of(int table) { return table == 0 ? kSplitNarrow : kSplitWide; }
 constexpr int kBlock = 256;
 constexpr int kUnroll = 4;       // entries in flight per lane group
 // A matrix too small to fill the chip finishes when its longest row does: that row's entries are a
@@ -771,7 +771,7 @@ static int launch_variant(const SpmmCall& a) {
     pv.nnz = p->nnz;
     pv.n_chunks = lt.n_chunks;
     pv.chunk_blocks = ceil_div(ceil_div(lt.n_chunks, kGroups), kWaves);
-    pv.split = split_of(ti);
+    pv.split = p->split[ti];
     pv.chunk_len = p->chunk_len ? p->chunk_len : pv.split;
     pv.strip_row = p->strip_row;
     pv.chunk_long = lt.chunk_long;
@@ -879,8 +879,15 @@ extern "C" {
 
 int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, gcn_spmm_plan** plan_out,
                          void* stream) {
+    return gcn_spmm_plan_create_split(n_rows, n_cols, nnz, indptr, 0, plan_out, stream);
+}
+
+int gcn_spmm_plan_create_split(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, int64_t split_entries,
+                               gcn_spmm_plan** plan_out, void* stream) {
     if (!plan_out) return fail(GCN_ERR_BAD_ARG, "plan_out is null");
     *plan_out = nullptr;
+    if (split_entries < 0 || (split_entries > 0 && split_entries < 16) || split_entries > kSplitWide)
+        return fail(GCN_ERR_BAD_ARG, "split_entries must be 0 (default) or in [16, %d]", kSplitWide);
     if (n_rows < 0 || n_cols < 0 || nnz < 0 || n_rows > INT32_MAX - 1 || n_cols > INT32_MAX)
         return fail(GCN_ERR_BAD_ARG, "bad shape %lld x %lld, nnz %lld", (long long)n_rows, (long long)n_cols,
                     (long long)nnz);
@@ -896,6 +903,9 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
     // on a small matrix a chunk is a chain of dependent batches like any row: keep it short (the rows it
     // applies to are summed chunk-wise either way)
     p->chunk_len = p->strip_nnz < kStripNnz ? kChunkSmall : 0;
+    p->split[0] = split_entries ? (int)std::min<int64_t>(split_entries, kSplitNarrow) : kSplitNarrow;
+    p->split[1] = split_entries ? (int)split_entries : kSplitWide;
+    if (p->chunk_len > p->split[0]) p->chunk_len = p->split[0];
     p->n_strips = std::max<int64_t>(1, ceil_div(work, p->strip_nnz));
     p->strip_row = nullptr;
     for (int t = 0; t < 2; ++t) {
@@ -931,9 +941,9 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
     strip_rows_kernel<<<(unsigned)ceil_div(p->n_strips + 1, kBlock), kBlock, 0, st>>>(
         n_rows, indptr, p->n_strips, p->strip_nnz, p->strip_row);
     PLAN_TRY(hipGetLastError());
-    // rows longer than the smaller split threshold (at most nnz / (kSplitNarrow + 1) of them); the table
+    // rows longer than the smaller split threshold (at most nnz / (that threshold + 1) of them); the table
     // for the larger threshold is the subset of the same list
-    const int64_t cap = nnz / (kSplitNarrow + 1);
+    const int64_t cap = nnz / (p->split[0] + 1);
     if (cap > 0 && n_rows > 0) {
         PLAN_TRY(hipMalloc(&d_rows, (size_t)cap * sizeof(int32_t)));
         PLAN_TRY(hipMalloc(&d_starts, (size_t)cap * sizeof(int64_t)));
@@ -941,7 +951,7 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
         PLAN_TRY(hipMalloc(&d_count, sizeof(unsigned long long)));
         PLAN_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
         collect_long_rows_kernel<<<(unsigned)ceil_div(n_rows, kBlock), kBlock, 0, st>>>(
-            n_rows, indptr, kSplitNarrow, cap, d_rows, d_starts, d_ends, d_count);
+            n_rows, indptr, p->split[0], cap, d_rows, d_starts, d_ends, d_count);
         PLAN_TRY(hipGetLastError());
         unsigned long long count = 0;
         PLAN_TRY(hipMemcpyAsync(&count, d_count, sizeof(count), hipMemcpyDeviceToHost, st));
@@ -961,7 +971,7 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
             for (size_t i = 0; i < count; ++i) order[i] = (int64_t)i;
             std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return rows[x] < rows[y]; });
             for (int t = 0; t < 2; ++t) {
-                const int64_t split = split_of(t);
+                const int64_t split = p->split[t];
                 std::vector<int32_t> long_row;
                 std::vector<int64_t> long_chunk;
                 std::vector<int32_t> chunk_long;
@@ -1036,7 +1046,7 @@ int gcn_spmm_plan_info(const gcn_spmm_plan* plan, int64_t* what4) {
     what4[0] = plan->n_strips;
     what4[1] = plan->table[0].n_long;
     what4[2] = plan->table[0].n_chunks;
-    what4[3] = kSplitNarrow;
+    what4[3] = plan->split[0];
     return GCN_OK;
 }
 

@@ -48,7 +48,7 @@ class _SpmmFn(torch.autograd.Function):
         if ctx.fuse_relu:
             out, = ctx.saved_tensors
             grad = sparse.dropout(grad, 1.0, 0, 0, gate=out)      # grad where out > 0, else 0
-        return None, sparse.spmm(ctx.a.transpose(), grad), None
+        return None, sparse.spmm(ctx.a.transpose(for_gradient=True), grad), None
 
 
 class _SpmmDropoutFn(torch.autograd.Function):
@@ -62,7 +62,7 @@ class _SpmmDropoutFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        gw = sparse.spmm_dropout(ctx.x.transpose(), grad, ctx.keep_prob, ctx.seed, ctx.stream_id)
+        gw = sparse.spmm_dropout(ctx.x.transpose(for_gradient=True), grad, ctx.keep_prob, ctx.seed, ctx.stream_id)
         return None, gw, None, None, None
 
 

@@ -44,13 +44,20 @@ def _ld(x):
     return x.stride(0) if x.shape[0] > 1 else max(x.shape[1], 1)
 
 
+GRADIENT_SPLIT = 64                 # split threshold of the plans of small transposed matrices
+SMALL_MATRIX_WORK = 8192 * 256      # entries + 4 per row below which 256-entry strips cannot fill the chip
+
+
 class SpmmPlan(object):
     """Owner of a ``gcn_spmm_plan`` (row-length analysis of one CSR structure)."""
 
-    def __init__(self, n_rows, n_cols, nnz, indptr):
+    def __init__(self, n_rows, n_cols, nnz, indptr, split=0):
+        """``split``: rows longer than this many entries are summed in chunks (0: the library's
+        defaults, under which every row of up to 256 entries keeps the serial order of its additions)."""
         _require_cuda(indptr)
         handle = ctypes.c_void_p()
-        _lib.call('gcn_spmm_plan_create', n_rows, n_cols, nnz, _p(indptr), ctypes.byref(handle), _stream())
+        _lib.call('gcn_spmm_plan_create_split', n_rows, n_cols, nnz, _p(indptr), int(split), ctypes.byref(handle),
+                  _stream())
         self.handle = handle
         info = (ctypes.c_int64 * 4)()
         _lib.call('gcn_spmm_plan_info', self.handle, info)
@@ -121,7 +128,7 @@ class DeviceCSR(object):
     @property
     def plan(self):
         if self._plan is None:
-            self._plan = SpmmPlan(self.n_rows, self.n_cols, self.nnz, self.indptr)
+            self._plan = SpmmPlan(self.n_rows, self.n_cols, self.nnz, self.indptr, getattr(self, 'plan_split', 0))
         return self._plan
 
     def check_indices(self):
@@ -129,11 +136,20 @@ class DeviceCSR(object):
         reference's TensorFlow kernel makes per nonzero)."""
         _lib.call('gcn_check_indices', self.nnz, _p(self.indices), self.n_cols, _stream())
 
-    def transpose(self):
-        """Stable transpose (cached): the adjoint operand of the backward products."""
+    def transpose(self, for_gradient=False):
+        """Stable transpose (cached): the adjoint operand of the backward products.
+
+        ``for_gradient``: the caller multiplies a gradient with it (X^T . dP, A^T . dZ), a product that is
+        compared with the reference to a tolerance.  On a matrix too small to fill the chip the
+        transpose's plan then cuts rows at 64 entries -- on a citation graph the rows of X^T are few and
+        long (a word's documents): Cora X^T . dP 34 -> 14 us.  The plan is made on first use, so the
+        first caller decides."""
         if self._t is None:
             self._t = csr_transpose(self)
-        return self._t
+        t = self._t
+        if for_gradient and t._plan is None and t.nnz + 4 * t.n_rows < SMALL_MATRIX_WORK:
+            t.plan_split = GRADIENT_SPLIT
+        return t
 
     @classmethod
     def from_scipy(cls, m, device='cuda'):

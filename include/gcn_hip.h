@@ -133,6 +133,15 @@ typedef struct gcn_spmm_plan gcn_spmm_plan;
  * rows, chunk tables for rows longer than the split thresholds.  [sync] */
 int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, gcn_spmm_plan** plan_out,
                          void* stream);
+
+/* The same with the split threshold chosen by the caller: rows longer than split_entries (16..1024;
+ * 0 = the defaults, 256 / 1024 entries for narrow / wide dense operands) are summed in chunks.  For
+ * the operands of the gradient products that optimizer.minimize derives (gcn/models.py:86), e.g.
+ * X^T of a citation graph, whose rows are long and few: a lower threshold trades the serial order of
+ * the additions in rows between the two thresholds (results still within 1e-5) for parallelism.
+ * [sync] */
+int gcn_spmm_plan_create_split(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, int64_t split_entries,
+                               gcn_spmm_plan** plan_out, void* stream);
 int gcn_spmm_plan_destroy(gcn_spmm_plan* plan);
 /* host-side facts about a plan: what[0]=n_strips, [1]=rows longer than the split threshold, [2]=their
  * chunks, [3]=the split threshold (the smallest one: rows up to it are summed serially for every width) */

@@ -212,6 +212,16 @@ def test_sparse_dropout_product_bit_exact(dataset_fx, oracle, keep_prob):
     assert np.array_equal(out_t[short], ref_t[short])
     ref_t64 = oracle.spmm_csr_f64(np.cumsum(tp2), ti[kt], tv[kt], g)
     assert np.abs(out_t - ref_t64).max() <= REL_TOL * np.abs(ref_t64).max()
+    # the plan a gradient product asks for: rows cut at 64 entries (parallelism on a small matrix);
+    # rows up to 64 entries keep the serial order, every row stays within the tolerance
+    x2 = _device_csr(n, f_in, ip, ix, xv)
+    xg = x2.transpose(for_gradient=True)
+    assert xg.plan.split_nnz == sparse.GRADIENT_SPLIT == 64 and xg.plan.n_long_rows > xt.plan.n_long_rows
+    out_g = sparse.spmm_dropout(xg, _t(g), keep_prob, seed, stream_id).cpu().numpy()
+    short = np.diff(tp) <= 64
+    assert np.array_equal(out_g[short], ref_t[short])
+    assert np.abs(out_g - ref_t64).max() <= REL_TOL * np.abs(ref_t64).max()
+    assert np.array_equal(sparse.spmm_dropout(xg, _t(g), keep_prob, seed, stream_id).cpu().numpy(), out_g)   # deterministic
 
 
 @pytest.mark.parametrize('f', [16, 256, 36, 5, 512])
