@@ -9,7 +9,7 @@
 namespace gcn {
 
 constexpr int kBlock = 256;
-constexpr int kXentTile = 32;   // wave-sized row groups per block of the loss kernel
+constexpr int kXentTile = 32;   // wave-sized row groups per block of the loss kernel on a large matrix
 
 // row_stats[i] = (CE_i * w_i, correct_i * w_i) with w_i = mask_i / mean(mask);
 // dlogits[i][c] = d(mean_i CE_i w_i) / d logits[i][c] = (softmax_ic * sum_c labels_ic - labels_ic) * w_i / n.
@@ -23,16 +23,17 @@ template <int G>
 __global__ void softmax_xent_group_kernel(int64_t n, int c, const float* __restrict__ logits, int64_t ldx,
                                           const int32_t* __restrict__ labels, int64_t ldl,
                                           const int32_t* __restrict__ mask, float mask_mean,
-                                          float* __restrict__ row_stats, float* __restrict__ dlogits, int64_t ldd) {
+                                          float* __restrict__ row_stats, float* __restrict__ dlogits, int64_t ldd,
+                                          int tile) {
     constexpr int kRows = 64 / G;                       // nodes per wave
     const float inv_n = 1.0f / (float)n;
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
-    // a block walks a contiguous stretch of kXentTile wave-sized row groups, its waves interleaved:
+    // a block walks a contiguous stretch of `tile` wave-sized row groups, its waves interleaved:
     // consecutive blocks read consecutive memory
     const int64_t n_groups = (n + kRows - 1) / kRows;
-    const int64_t g_begin = (int64_t)blockIdx.x * kXentTile;
-    const int64_t g_end = g_begin + kXentTile < n_groups ? g_begin + kXentTile : n_groups;
+    const int64_t g_begin = (int64_t)blockIdx.x * tile;
+    const int64_t g_end = g_begin + tile < n_groups ? g_begin + tile : n_groups;
     for (int64_t g = g_begin + (threadIdx.x >> 6); g < g_end; g += kBlock / 64) {   // uniform per wave: every lane takes part in the shuffles
         const int64_t i = g * kRows + lane / G;
         const bool live = i < n && sub < c;
@@ -123,9 +124,11 @@ static void launch_xent_group(int64_t n, int c, const float* logits, int64_t ldx
                               const int32_t* mask, float mask_mean, float* row_stats, float* dlogits, int64_t ldd,
                               hipStream_t stream) {
     const int64_t n_groups = ceil_div(n, (int64_t)(64 / G));
-    const int64_t blocks = ceil_div(n_groups, (int64_t)kXentTile);
+    // one group per wave until that gives more than ~8 blocks per CU (a citation graph: 85 blocks), then longer tiles
+    const int tile = (int)std::min<int64_t>(kXentTile, std::max<int64_t>(kBlock / 64, ceil_div(n_groups, 2048)));
+    const int64_t blocks = ceil_div(n_groups, (int64_t)tile);
     softmax_xent_group_kernel<G><<<(unsigned)blocks, kBlock, 0, stream>>>(n, c, logits, ldx, labels, ldl, mask, mask_mean,
-                                                                         row_stats, dlogits, ldd);
+                                                                         row_stats, dlogits, ldd, tile);
 }
 
 // g' = g + wd * p;  m += (1 - b1)(g' - m);  v += (1 - b2)(g'^2 - v);  p -= lr_t * m / (sqrt(v) + eps).
