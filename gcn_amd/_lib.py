@@ -67,6 +67,8 @@ SIGNATURES = {
     'gcn_gemm_tn_workspace_bytes': [_i64, _i64, _i64, ctypes.POINTER(ctypes.c_size_t)],
     'gcn_gather_rows_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp],
     'gcn_softmax_xent_f32': [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _vp],
+    'gcn_loss_summary_workspace_bytes': [_i64, _i64, ctypes.POINTER(ctypes.c_size_t)],
+    'gcn_loss_summary_f32': [_i64, _vp, _i64, _vp, _f32, _vp, _sz, _vp, _vp],
     'gcn_adam_f32': [_i64, _vp, _vp, _vp, _vp, _f32, _vp, _f32, _f32, _f32, _f32, _vp],
     'gcn_gemm_tn_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, ctypes.c_size_t, _vp],
 }

@@ -119,6 +119,74 @@ __global__ void softmax_xent_kernel(int64_t n, int c, const float* __restrict__ 
     }
 }
 
+// loss and accuracy of a step from the per-node rows of the loss kernel and the weights:
+//   out[0] = mean_i stats[i][0] + weight_decay * sum_j w_j^2 / 2     (gcn/models.py:92-99)
+//   out[1] = mean_i stats[i][1]                                       (gcn/models.py:106-108)
+// Sums are taken in float64 in a fixed order (thread-strided, then a tree inside the block, then the
+// blocks in order), so the result does not depend on scheduling.  One block writes the result itself;
+// more blocks leave three partial sums each in `partial` for loss_summary_final_kernel.
+constexpr int kSummaryBlock = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double* lds) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += lds[w];
+    return t;
+}
+
+__global__ __launch_bounds__(kSummaryBlock) void loss_summary_kernel(int64_t n, const float* __restrict__ stats,
+                                                                    int64_t n_w, const float* __restrict__ w,
+                                                                    float weight_decay, double* __restrict__ partial,
+                                                                    float* __restrict__ out) {
+    __shared__ double lds[kSummaryBlock / 64];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, sw = 0.0;
+    const float2* rows = reinterpret_cast<const float2*>(stats);
+    for (int64_t i = first; i < n; i += stride) {
+        const float2 r = rows[i];
+        s0 += (double)r.x;
+        s1 += (double)r.y;
+    }
+    for (int64_t j = first; j < n_w; j += stride) sw += (double)w[j] * (double)w[j];
+    s0 = block_sum(s0, lds);
+    s1 = block_sum(s1, lds);
+    sw = block_sum(sw, lds);
+    if (threadIdx.x == 0) {
+        if (gridDim.x == 1) {
+            out[0] = (float)(s0 / (double)n + 0.5 * (double)weight_decay * sw);
+            out[1] = (float)(s1 / (double)n);
+        } else {
+            partial[3 * blockIdx.x] = s0;
+            partial[3 * blockIdx.x + 1] = s1;
+            partial[3 * blockIdx.x + 2] = sw;
+        }
+    }
+}
+
+__global__ void loss_summary_final_kernel(int64_t n, int blocks, const double* __restrict__ partial, float weight_decay,
+                                          float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s0 = 0.0, s1 = 0.0, sw = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+        s0 += partial[3 * b];
+        s1 += partial[3 * b + 1];
+        sw += partial[3 * b + 2];
+    }
+    out[0] = (float)(s0 / (double)n + 0.5 * (double)weight_decay * sw);
+    out[1] = (float)(s1 / (double)n);
+}
+
+static inline int summary_blocks(int64_t n, int64_t n_w) {
+    const int64_t work = std::max(n, n_w);
+    return (int)std::min<int64_t>(256, std::max<int64_t>(1, work / (kSummaryBlock * 16)));
+}
+
 template <int G>
 static void launch_xent_group(int64_t n, int c, const float* logits, int64_t ldx, const int32_t* labels, int64_t ldl,
                               const int32_t* mask, float mask_mean, float* row_stats, float* dlogits, int64_t ldd,
@@ -180,6 +248,37 @@ int gcn_softmax_xent_f32(int64_t n, int64_t c, const float* logits, int64_t ldx,
     }
 #undef GCN_XENT_GROUP
     GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_loss_summary_workspace_bytes(int64_t n, int64_t n_weights, size_t* bytes) {
+    if (!bytes || n < 0 || n_weights < 0) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    const int blocks = summary_blocks(n, n_weights);
+    *bytes = blocks > 1 ? (size_t)blocks * 3 * sizeof(double) : 0;
+    return GCN_OK;
+}
+
+int gcn_loss_summary_f32(int64_t n, const float* row_stats, int64_t n_weights, const float* weights, float weight_decay,
+                         void* workspace, size_t workspace_bytes, float* out2, void* stream) {
+    if (n < 1 || n_weights < 0) return fail(GCN_ERR_BAD_ARG, "bad size: n=%lld n_weights=%lld", (long long)n,
+                                            (long long)n_weights);
+    if (!row_stats || !out2 || (n_weights > 0 && !weights)) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    if (((uintptr_t)row_stats & 7) != 0) return fail(GCN_ERR_BAD_ARG, "row_stats must be 8-byte aligned");
+    const int blocks = summary_blocks(n, n_weights);
+    hipStream_t st = (hipStream_t)stream;
+    if (blocks > 1) {
+        const size_t need = (size_t)blocks * 3 * sizeof(double);
+        if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 7) != 0)
+            return fail(GCN_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed (8-byte aligned)", workspace_bytes,
+                        need);
+    }
+    loss_summary_kernel<<<blocks, kSummaryBlock, 0, st>>>(n, row_stats, n_weights, weights, weight_decay,
+                                                         (double*)workspace, out2);
+    GCN_LAUNCH_CHECK();
+    if (blocks > 1) {
+        loss_summary_final_kernel<<<1, 64, 0, st>>>(n, blocks, (const double*)workspace, weight_decay, out2);
+        GCN_LAUNCH_CHECK();
+    }
     return GCN_OK;
 }
 

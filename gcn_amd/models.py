@@ -109,9 +109,20 @@ class GCN_MLP(object):
             self.layers.append(layer)
             is_sparse = False
             prev = layer
+        # every variable is a view into one buffer, so that the weight-decay term of the loss is one pass
+        # over it inside the kernel that also averages the loss and accuracy rows
+        total = sum(var.numel() for layer in self.layers for var in layer.vars.values())
+        first = next(var for layer in self.layers for var in layer.vars.values())
+        self._flat_weights = torch.empty(total, dtype=torch.float32, device=first.device)
+        pos = 0
         for layer in self.layers:
-            for key, var in layer.vars.items():
-                self.vars[layer.name + '/' + key] = var
+            for key, var in list(layer.vars.items()):
+                view = self._flat_weights[pos:pos + var.numel()].view(var.shape)
+                with torch.no_grad():
+                    view.copy_(var)
+                layer.vars[key] = view.requires_grad_(True)
+                pos += var.numel()
+                self.vars[layer.name + '/' + key] = layer.vars[key]
         self.optimizer = TfAdam(self._trainable(), self.model_config['learning_rate'])
 
     def _trainable(self):
@@ -173,10 +184,18 @@ class GCN_MLP(object):
             self._device_cache[('mask_mean', id(mask))] = hit
         return hit[1]
 
-    def _weight_decay_term(self):
-        """gcn/models.py:94-96: weight_decay * l2_loss(var) summed over every variable of every layer."""
+    def _loss_and_accuracy(self, stats):
+        """[loss, accuracy] on the device: gcn/models.py:92-99 (weight_decay * l2_loss(var) over every
+        variable of every layer plus the masked cross entropy) and 106-108, from the loss kernel's rows."""
         wd = self.model_config['weight_decay']
-        return sum(wd * (var * var).sum() / 2 for layer in self.layers for var in layer.vars.values())
+        flat = self._flat_weights
+        end = flat.data_ptr() + 4 * flat.numel()
+        if all(flat.data_ptr() <= v.data_ptr() < end for v in self._trainable()):
+            return sparse.loss_summary(stats, flat, wd)
+        # a variable was replaced by a tensor of the caller's: sum over the variables as they are
+        means = stats.mean(dim=0)
+        reg = sum(wd * (var * var).sum() / 2 for var in self._trainable())
+        return torch.stack([means[0] + reg, means[1]])
 
     # ------------------------------------------------------------------ #
     # the train step as one HIP graph
@@ -214,9 +233,7 @@ class GCN_MLP(object):
                 with torch.no_grad():
                     rec['outputs'] = outputs.detach()
                     if 'loss' in keys or 'accuracy' in keys:
-                        means = stats.mean(dim=0)
-                        rec['accuracy'] = means[1]
-                        rec['loss'] = means[0] + self._weight_decay_term() if 'loss' in keys else means[0]
+                        rec['summary2'] = self._loss_and_accuracy(stats)     # with the weights of this forward
                     if 'prediction' in keys:
                         rec['prediction'] = torch.softmax(outputs.detach(), dim=1)
                 self.optimizer.step_fused(grads, rec['lr_t'], self.model_config['weight_decay'])
@@ -252,10 +269,12 @@ class GCN_MLP(object):
         rec['graph'].replay()
         self.global_step += 1
         out = {'opt_op': None, 'summary': None}
-        if 'loss' in keys:
-            out['loss'] = np.float32(rec['loss'].item())
-        if 'accuracy' in keys:
-            out['accuracy'] = np.float32(rec['accuracy'].item())
+        if 'loss' in keys or 'accuracy' in keys:
+            loss, accuracy = rec['summary2'].tolist()                    # one read-back for both
+            if 'loss' in keys:
+                out['loss'] = np.float32(loss)
+            if 'accuracy' in keys:
+                out['accuracy'] = np.float32(accuracy)
         if 'outputs' in keys:
             out['outputs'] = graph.to_numpy(rec['outputs'])
         if 'prediction' in keys:
@@ -278,10 +297,9 @@ class GCN_MLP(object):
             if need_stats:      # loss rows, accuracy rows and d loss / d logits in one pass over the logits
                 stats, dlogits = sparse.softmax_xent(outputs.detach(), labels, mask, self._mask_mean(mask),
                                                      want_grad=train)
-                stats = stats.mean(dim=0)
-            if 'loss' in keys:
-                with torch.no_grad():
-                    loss = stats[0] + self._weight_decay_term()        # with the weights of this run's forward
+                if 'loss' in keys or 'accuracy' in keys:
+                    with torch.no_grad():
+                        summary = self._loss_and_accuracy(stats)       # with the weights of this run's forward
             if train:
                 params = self._trainable()
                 grads = torch.autograd.grad(outputs, params, grad_outputs=dlogits)
@@ -295,10 +313,12 @@ class GCN_MLP(object):
                 out['outputs'] = graph.to_numpy(outputs)
             if 'prediction' in keys:
                 out['prediction'] = graph.to_numpy(torch.softmax(outputs, dim=1))      # models.py:89-90
-            if 'loss' in keys:
-                out['loss'] = np.float32(loss.item())
-            if 'accuracy' in keys:
-                out['accuracy'] = np.float32(stats[1].item())                                   # models.py:106-108
+            if 'loss' in keys or 'accuracy' in keys:
+                loss, accuracy = summary.tolist()                                               # one read-back for both
+                if 'loss' in keys:
+                    out['loss'] = np.float32(loss)
+                if 'accuracy' in keys:
+                    out['accuracy'] = np.float32(accuracy)                                      # models.py:106-108
             if 'accuracy_of_class' in keys:
                 m = mask.to(torch.float32)
                 out['accuracy_of_class'] = [

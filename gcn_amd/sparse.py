@@ -515,6 +515,26 @@ def softmax_xent(logits, labels, mask, mask_mean, want_grad=True):
     return stats, grad
 
 
+def loss_summary(stats, weights_flat, weight_decay):
+    """[loss, accuracy] of a step as a 2-element device tensor: the means of the two columns of
+    ``stats`` (from softmax_xent) plus weight_decay * sum(w^2) / 2 over ``weights_flat`` (all variables
+    in one buffer; None or empty: no weight-decay term)."""
+    _require_cuda(stats)
+    n = stats.shape[0]
+    if stats.dtype != torch.float32 or tuple(stats.shape) != (n, 2) or not stats.is_contiguous():
+        raise ValueError('stats must be a contiguous float32 [n x 2] tensor')
+    n_w = 0 if weights_flat is None else weights_flat.numel()
+    if n_w and (weights_flat.dtype != torch.float32 or not weights_flat.is_contiguous()):
+        raise ValueError('weights must be one contiguous float32 buffer')
+    need = ctypes.c_size_t()
+    _lib.call('gcn_loss_summary_workspace_bytes', n, n_w, ctypes.byref(need))
+    ws = _workspace(need.value, stats.device) if need.value else None
+    out = torch.empty(2, dtype=torch.float32, device=stats.device)
+    _lib.call('gcn_loss_summary_f32', n, _p(stats), n_w, _p(weights_flat) if n_w else None, float(weight_decay),
+              _p(ws), need.value, _p(out), _stream())
+    return out
+
+
 def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, epsilon=1e-8, weight_decay=0.0):
     """In-place Adam update of one contiguous float32 variable; ``lr_t`` is a float or a 0-d device tensor."""
     _require_cuda(param, grad, m, v)

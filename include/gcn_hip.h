@@ -264,6 +264,16 @@ int gcn_softmax_xent_f32(int64_t n, int64_t c, const float* logits, int64_t ldx,
                          const int32_t* mask, float mask_mean, float* row_stats, float* dlogits, int64_t ldd,
                          void* stream);
 
+/* Loss and accuracy of a step from the rows gcn_softmax_xent_f32 wrote and the model's weights:
+ *   out2[0] = mean_i row_stats[i][0] + weight_decay * sum_j weights[j]^2 / 2
+ *             (`loss += weight_decay * tf.nn.l2_loss(var)` for every variable, then the masked cross
+ *             entropy: gcn/models.py:92-99; the variables lie in one buffer of n_weights floats)
+ *   out2[1] = mean_i row_stats[i][1]   (gcn/models.py:106-108)
+ * float64 sums in a fixed order.  workspace: gcn_loss_summary_workspace_bytes (0 for small inputs). */
+int gcn_loss_summary_workspace_bytes(int64_t n, int64_t n_weights, size_t* bytes);
+int gcn_loss_summary_f32(int64_t n, const float* row_stats, int64_t n_weights, const float* weights, float weight_decay,
+                         void* workspace, size_t workspace_bytes, float* out2, void* stream);
+
 /* One tf.train.AdamOptimizer step on one variable (gcn/models.py:35-38) with the weight-decay term of
  * the loss (gcn/models.py:94-96) folded into the gradient: g' = g + weight_decay * p;
  * m += (1 - beta1)(g' - m); v += (1 - beta2)(g'^2 - v); p -= lr_t * m / (sqrt(v) + epsilon), where

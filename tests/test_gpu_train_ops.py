@@ -93,3 +93,21 @@ def test_adam_steps_follow_the_oracle(oracle, shape):
             sparse.adam_step(p, _t(g), m, v, lr_dev if on_device else lr_t, weight_decay=float(wd))
         assert np.abs(p.cpu().numpy() - ref_w[0]).max() <= 1e-5 * np.abs(ref_w[0]).max()
         assert np.abs(m.cpu().numpy() - adam.m[0]).max() <= 1e-6 * max(np.abs(adam.m[0]).max(), 1e-30)
+
+
+@pytest.mark.parametrize('n,n_w', [(2708, 23040), (1, 0), (100003, 7), (3_000_000, 70000)])
+def test_loss_summary_is_the_means_plus_weight_decay(n, n_w):
+    """out = [mean(stats[:, 0]) + wd * sum(w^2) / 2, mean(stats[:, 1])] (gcn/models.py:92-99, 106-108), one
+    block or several with the partial sums added in a fixed order; tolerance 1e-6 relative (float64 sums)."""
+    import torch
+    from gcn_amd import sparse
+    gen = torch.Generator().manual_seed(n)
+    stats = torch.rand((n, 2), generator=gen).cuda()
+    w = (torch.rand(n_w, generator=gen) - 0.5).cuda() if n_w else None
+    wd = 5e-4
+    out = sparse.loss_summary(stats, w, wd)
+    ref_loss = float(stats[:, 0].double().mean()) + (wd * float((w.double() ** 2).sum()) / 2 if n_w else 0.0)
+    ref_acc = float(stats[:, 1].double().mean())
+    got_loss, got_acc = out.tolist()
+    assert abs(got_loss - ref_loss) <= 1e-6 * abs(ref_loss) and abs(got_acc - ref_acc) <= 1e-6 * abs(ref_acc)
+    assert torch.equal(out, sparse.loss_summary(stats, w, wd))          # deterministic
