@@ -12,7 +12,7 @@ import torch
 
 from . import graph, sparse
 from .dist import HaloPlan, all_reduce_sum, column_chunks, column_shares, halo_product
-from .layers import _GemmFn
+from .layers import _GatedGemmFn, _GemmFn
 from .models import TfAdam
 
 
@@ -49,27 +49,6 @@ class _HaloSpmmFn(torch.autograd.Function):
         plan = ctx.plan
         # symmetric support: rows of A^T are rows of A
         return None, _product(plan, grad.contiguous(), False, ctx.chunks), None, None, None, None
-
-
-class _GatedGemmFn(torch.autograd.Function):
-    """h_dropped . W where h_dropped = dropout(relu(z)) came out of a product's store.  The gradient it
-    returns for its left operand is the gradient of z: (dP . W^T) / keep where h_dropped > 0, else 0 --
-    the dropout's and the ReLU's backward in the store of the product dP . W^T (h_dropped is positive
-    exactly where the unit was active and kept), instead of a pass over the activations."""
-
-    @staticmethod
-    def forward(ctx, h_dropped, w, keep_prob):
-        ctx.save_for_backward(h_dropped, w)
-        ctx.keep_prob = keep_prob
-        return sparse.gemm(h_dropped, w)
-
-    @staticmethod
-    def backward(ctx, grad):
-        h, w = ctx.saved_tensors
-        grad = grad.contiguous()
-        d_h = sparse.gemm_gated(grad, w, h, ctx.keep_prob, trans_b=True) if ctx.needs_input_grad[0] else None
-        d_w = sparse.gemm_tn(h, grad) if ctx.needs_input_grad[1] else None
-        return d_h, d_w, None
 
 
 class _ShardDropoutFn(torch.autograd.Function):

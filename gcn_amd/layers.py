@@ -33,22 +33,29 @@ def relu(x):
 # autograd bindings of the HIP operators
 # --------------------------------------------------------------------------- #
 class _SpmmFn(torch.autograd.Function):
-    """out = act(A . B); backward: dB = A^T . (dOut gated by the ReLU)."""
+    """out = act(A . B); backward: dB = A^T . (dOut gated by the ReLU).
+
+    With ``out_dropout`` (a sparse.OutDropout: the NEXT layer's input dropout) the product stores
+    dropout(act(A . B)) and the consumer -- _GatedGemmFn -- applies the backward of both the dropout and
+    the ReLU in the store of its own gradient product: the gradient that arrives here is already the
+    one of A . B."""
 
     @staticmethod
-    def forward(ctx, a, b, fuse_relu):
-        out = sparse.spmm(a, b, relu=fuse_relu)
-        ctx.a, ctx.fuse_relu = a, fuse_relu
-        if fuse_relu:
+    def forward(ctx, a, b, fuse_relu, out_dropout=None):
+        out = sparse.spmm(a, b, relu=fuse_relu, out_dropout=out_dropout)
+        ctx.a = a
+        ctx.gate = fuse_relu and out_dropout is None
+        if ctx.gate:
             ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        if ctx.fuse_relu:
+        if ctx.gate:
             out, = ctx.saved_tensors
             grad = sparse.dropout(grad, 1.0, 0, 0, gate=out)      # grad where out > 0, else 0
-        return None, sparse.spmm(ctx.a.transpose(for_gradient=True), grad), None
+        # the support keeps its default plan (every row of up to 256 entries summed in storage order)
+        return None, sparse.spmm(ctx.a.transpose(), grad.contiguous()), None, None
 
 
 class _SpmmDropoutFn(torch.autograd.Function):
@@ -94,6 +101,28 @@ class _GemmFn(torch.autograd.Function):
         return ga, gw
 
 
+class _GatedGemmFn(torch.autograd.Function):
+    """h_dropped . W where h_dropped = dropout(relu(z)) came out of a product's store (_SpmmFn with
+    ``out_dropout``).  The gradient it returns for its left operand is the gradient of z:
+    (dP . W^T) / keep where h_dropped > 0, else 0 -- the dropout's and the ReLU's backward in the store
+    of the product dP . W^T (h_dropped is positive exactly where the unit was active and kept) instead of
+    two passes over the activations."""
+
+    @staticmethod
+    def forward(ctx, h_dropped, w, keep_prob):
+        ctx.save_for_backward(h_dropped, w)
+        ctx.keep_prob = keep_prob
+        return sparse.gemm(h_dropped, w)
+
+    @staticmethod
+    def backward(ctx, grad):
+        h, w = ctx.saved_tensors
+        grad = grad.contiguous()
+        d_h = sparse.gemm_gated(grad, w, h, ctx.keep_prob, trans_b=True) if ctx.needs_input_grad[0] else None
+        d_w = sparse.gemm_tn(h, grad) if ctx.needs_input_grad[1] else None
+        return d_h, d_w, None
+
+
 class DroppedSparse(object):
     """A sparse matrix with a pending ``sparse_dropout``: the mask is applied inside the next product."""
 
@@ -130,16 +159,18 @@ def dense_dropout(x, keep_prob, seed=None, stream_id=None):
                             next_stream_id() if stream_id is None else stream_id)
 
 
-def dot(x, y, sparse=False, fuse_relu=False):
+def dot(x, y, sparse=False, fuse_relu=False, out_dropout=None, dropped_input=None):
     """Wrapper for the two matmuls of the reference (gcn/layers.py:28-34): ``sparse=True`` is
     tf.sparse_tensor_dense_matmul (x a DeviceCSR, possibly with a pending dropout), otherwise
-    tf.matmul.  ``fuse_relu`` is this build's extension: ReLU in the product's epilogue."""
+    tf.matmul.  This build's extensions: ``fuse_relu`` -- ReLU in the product's epilogue;
+    ``out_dropout`` (sparse product with fuse_relu) -- the next layer's input dropout in its store;
+    ``dropped_input`` (dense product) -- the keep probability of such a dropout already carried by x."""
     if sparse:
         if isinstance(x, DroppedSparse):
             res = _SpmmDropoutFn.apply(x.csr, y, x.keep_prob, x.seed, x.stream_id)
             return torch.relu(res) if fuse_relu else res
-        return _SpmmFn.apply(x, y, fuse_relu)
-    res = _GemmFn.apply(x, y)
+        return _SpmmFn.apply(x, y, fuse_relu, out_dropout if fuse_relu else None)
+    res = _GatedGemmFn.apply(x, y, dropped_input) if dropped_input is not None else _GemmFn.apply(x, y)
     return torch.relu(res) if fuse_relu else res
 
 
@@ -216,6 +247,11 @@ class GraphConvolution(Layer):
         if self.bias:
             self.vars['bias'] = inits.zeros([output_dim], name=self.name + '/bias')
         self.stream_id = None          # set per run by the model: which dropout stream this layer draws
+        # set per run by the model when two layers follow each other: this layer's product stores its
+        # output with the next layer's input dropout applied (a sparse.OutDropout), and the next layer is
+        # told the keep probability its input already carries
+        self.next_dropout = None
+        self.input_dropped = None
 
     def _dropout_rate(self):
         d = self.dropout
@@ -223,10 +259,20 @@ class GraphConvolution(Layer):
             d = d.default if getattr(d, 'value', None) is None else d.value
         return float(d)
 
+    def can_drop_output(self):
+        """Whether this layer's activation and the next layer's dropout can go into its product's store."""
+        return (self.act is relu) and not self.bias and len(self.support) == 1
+
+    def takes_dropped_input(self):
+        return not self.sparse_inputs and not self.featureless
+
     def _call(self, x):
         keep_prob = 1.0 - self._dropout_rate()
         stream_id = self.stream_id if self.stream_id is not None else next_stream_id()
-        if self.sparse_inputs:
+        dropped_input = self.input_dropped if self.takes_dropped_input() else None
+        if dropped_input is not None:
+            pass                                           # the producer stored x already dropped
+        elif self.sparse_inputs:
             nnz = _resolve(self.num_features_nonzero) if isinstance(self.num_features_nonzero, graph.Placeholder) \
                 else self.num_features_nonzero
             x = sparse_dropout(x, keep_prob, nnz, stream_id=stream_id)
@@ -237,10 +283,12 @@ class GraphConvolution(Layer):
         supports = []
         for i in range(len(self.support)):
             if not self.featureless:
-                pre_sup = dot(x, self.vars['weights_' + str(i)], sparse=self.sparse_inputs)
+                pre_sup = dot(x, self.vars['weights_' + str(i)], sparse=self.sparse_inputs,
+                              dropped_input=dropped_input)
             else:
                 pre_sup = self.vars['weights_' + str(i)]
-            supports.append(dot(_resolve(self.support[i]), pre_sup, sparse=True, fuse_relu=fuse))
+            supports.append(dot(_resolve(self.support[i]), pre_sup, sparse=True, fuse_relu=fuse,
+                                out_dropout=self.next_dropout if fuse else None))
         output = supports[0]
         for s in supports[1:]:
             output = output + s

@@ -166,15 +166,32 @@ class GCN_MLP(object):
             self._device_cache[key] = hit
         return hit[1]
 
-    def _forward(self):
-        """gcn/models.py:54-69: every layer's dropout draws its own stream of this run."""
+    def _forward(self, stream_base=None):
+        """gcn/models.py:54-69: every layer's dropout draws its own stream of this run (``stream_base``:
+        0 when the run's share of the stream id is added on the device, as in a recorded step)."""
         self.activations = [self.inputs.value]
         hidden = self.inputs.value
+        base = self._run_counter * 64 if stream_base is None else stream_base
         for li, layer in enumerate(self.layers):
-            layer.stream_id = self._run_counter * 64 + li
+            layer.stream_id = base + li
+        self._plan_fused_dropout()
+        for layer in self.layers:
             hidden = layer(hidden)
             self.activations.append(hidden)
         return hidden
+
+    def _plan_fused_dropout(self):
+        """Where a ReLU layer feeds a dense-input layer that drops its input, the dropout (the same
+        decisions: stream of the consuming layer, element id row * width + column) is applied in the
+        store of the producing layer's product, and its backward in the store of the consumer's gradient
+        product."""
+        for layer in self.layers:
+            layer.next_dropout = layer.input_dropped = None
+        for producer, consumer in zip(self.layers, self.layers[1:]):
+            keep = 1.0 - consumer._dropout_rate()
+            if keep < 1.0 and producer.can_drop_output() and consumer.takes_dropped_input():
+                producer.next_dropout = sparse.OutDropout(keep, graph.get_random_seed(), consumer.stream_id)
+                consumer.input_dropped = keep
 
     def _mask_mean(self, mask):
         """mean(mask) as a host float, computed once per fed mask."""
@@ -223,11 +240,9 @@ class GCN_MLP(object):
                'lr_t': torch.zeros((), dtype=torch.float32, device=dev)}
 
         def body():
-            for li, layer in enumerate(self.layers):
-                layer.stream_id = li                       # + 64 * run counter, read from rec['offset'] by the kernels
-            with sparse.stream_offset(rec['offset']):
+            with sparse.stream_offset(rec['offset']):          # 64 * run counter, added to the stream ids by the kernels
                 with torch.enable_grad():
-                    outputs = self._forward()
+                    outputs = self._forward(stream_base=0)
                     stats, dlogits = sparse.softmax_xent(outputs.detach(), labels, mask, mask_mean)
                     grads = torch.autograd.grad(outputs, params, grad_outputs=dlogits)
                 with torch.no_grad():

@@ -132,7 +132,9 @@ def test_training_mode_uses_the_same_dropout_masks_as_the_oracle(oracle):
     outputs, loss = sess.run([model.outputs, model.loss], feed_dict=feed)
     run = model._run_counter
     logits = ref.forward(dropout=0.5, seed=77, stream_ids=[run * 64 + 0, run * 64 + 1])
-    assert np.array_equal(model.activations[1].cpu().numpy(), np.maximum(ref.cache['z'][0], 0))
+    # the first layer's product stores its ReLU output with the second layer's input dropout applied:
+    # the oracle's dropped hidden matrix, bit for bit
+    assert np.array_equal(model.activations[1].cpu().numpy(), ref.cache['hin'][1])
     assert _close(outputs, logits)
     # about half of X's entries were dropped, and a second run draws a different mask
     assert 0.45 < ref.cache['xmask'].mean() < 0.55
