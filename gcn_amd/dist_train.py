@@ -63,17 +63,53 @@ class _ShardDropoutFn(torch.autograd.Function):
         return sparse.dropout(grad, keep_prob, seed, stream_id, index_offset=index_offset), None, None, None, None
 
 
+class _AggregatedFirstLayerFn(torch.autograd.Function):
+    """act(S . W) for S = A . dropout(X), the first layer taken in the order (A . X') . W.
+
+    A . (X' . W) and (A . X') . W are the same matrix up to rounding; when the input is not wider than
+    the layer, aggregating first costs the same forward product and makes the backward one unnecessary:
+    X has no gradient, and dW = S^T . dZ needs only S, which the forward pass already holds -- where the
+    reference's order needs A^T . dZ, a second product as wide as the layer, before X'^T . (A^T . dZ)."""
+
+    @staticmethod
+    def forward(ctx, s, w, relu, out_dropout):
+        z = sparse.gemm(s, w, relu=relu)
+        ctx.gate = relu and out_dropout is None
+        if out_dropout is not None:        # the next layer's input dropout; its backward is the consumer's (_GatedGemmFn)
+            d = out_dropout
+            z = sparse.dropout(z, d.keep_prob, d.seed, d.stream_id, index_offset=d.index_offset)
+        if ctx.gate:
+            ctx.save_for_backward(s, z)
+        else:
+            ctx.save_for_backward(s)
+        return z
+
+    @staticmethod
+    def backward(ctx, grad):
+        if ctx.gate:
+            s, z = ctx.saved_tensors
+            grad = sparse.dropout(grad, 1.0, 0, 0, gate=z)
+        else:
+            s, = ctx.saved_tensors
+        return None, sparse.gemm_tn(s, grad.contiguous()), None, None
+
+
 class ShardedGCN(object):
-    """Dense-feature GCN (connection 'c' * L) over a ``RowShardedCSR`` with a symmetric support."""
+    """Dense-feature GCN (connection 'c' * L) over a ``RowShardedCSR`` with a symmetric support.
+
+    ``aggregate_first`` (default: when the input is not wider than the first layer): the first layer is
+    computed as (A . X') . W0 instead of A . (X' . W0) -- the same matrix up to rounding -- which drops the
+    backward product of that layer (see _AggregatedFirstLayerFn)."""
 
     def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
-                 seed=0, group=None, chunks=4):
+                 seed=0, group=None, chunks=4, aggregate_first=None):
         self.shard, self.group = shard, group
         # ranges of feature columns an exchange is pipelined over: a count, or a tuple of width shares
         self.chunks = chunks if shard.world > 1 else 1
         self.plan = HaloPlan(shard, group=group)
         self.dropout, self.wd, self.seed = float(dropout), float(weight_decay), int(seed)
         sizes = [f_in] + list(layer_size) + [n_classes]
+        self.aggregate_first = (f_in <= sizes[1]) if aggregate_first is None else bool(aggregate_first)
         dev = shard.local.device
         g = torch.Generator(device=dev)
         g.manual_seed(self.seed)                       # every rank draws the same replicated weights
@@ -100,14 +136,21 @@ class ShardedGCN(object):
         h = x_local
         last = len(self.weights) - 1
         for li, w in enumerate(self.weights):
-            if drop and li == 0:
-                offset = self.shard.row_begin * h.shape[1]
-                h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64, offset)
-            p = _GatedGemmFn.apply(h, w, keep) if drop and li > 0 else _GemmFn.apply(h, w)
             next_drop = None
             if drop and li != last:
                 next_drop = sparse.OutDropout(keep, self.seed, self.step_count * 64 + li + 1,
                                               self.shard.row_begin * w.shape[1])
+            if li == 0 and self.aggregate_first:
+                if drop:                                   # the input has no gradient: a plain pass
+                    h = sparse.dropout(h, keep, self.seed, self.step_count * 64,
+                                       index_offset=self.shard.row_begin * h.shape[1])
+                s = _product(self.plan, h, False, self.chunks)
+                h = _AggregatedFirstLayerFn.apply(s, w, li != last, next_drop)
+                continue
+            if drop and li == 0:
+                offset = self.shard.row_begin * h.shape[1]
+                h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64, offset)
+            p = _GatedGemmFn.apply(h, w, keep) if drop and li > 0 else _GemmFn.apply(h, w)
             h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop)
         return h
 

@@ -107,7 +107,7 @@ def test_exchange_in_flight_over_rccl(tmp_path):
     assert (tmp_path / 'ok').exists()
 
 
-def _train_worker(rank, world, port, result_dir, scale, steps):
+def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first):
     if world > 1:
         faulthandler.dump_traceback_later(90, exit=True)
     sys.path.insert(0, ROOT)
@@ -130,7 +130,8 @@ def _train_worker(rank, world, port, result_dir, scale, steps):
         cls = torch.randint(0, classes, (n,), generator=gen)
         labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32)[r0:r1].cuda()
         mask = (torch.rand(n, generator=gen) < 0.05).to(torch.int32)[r0:r1].cuda()
-        model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9)
+        model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9,
+                           aggregate_first=aggregate_first)
         losses = [float(model.train_step(x, labels, mask)) for _ in range(steps)]
         if rank == 0:
             np.save(os.path.join(result_dir, 'loss_w%d.npy' % world), np.array(losses))
@@ -140,14 +141,16 @@ def _train_worker(rank, world, port, result_dir, scale, steps):
             dist.destroy_process_group()
 
 
-def test_sharded_training_step_matches_single_gpu(tmp_path):
+@pytest.mark.parametrize('aggregate_first', [False, True])
+def test_sharded_training_step_matches_single_gpu(tmp_path, aggregate_first):
     """Forward + backward + Adam on 2 ranks (exchange of referenced rows in both directions, all-reduced
-    weight gradients, the unsplit dropout masks) against the same model on 1 rank."""
+    weight gradients, the unsplit dropout masks) against the same model on 1 rank, with the first layer
+    in the reference's order A . (X' . W) and in the order (A . X') . W that needs no backward product."""
     scale, steps = 13, 4
-    port = 29800 + (os.getpid() % 1000)
-    _train_worker(0, 1, port, str(tmp_path), scale, steps)
-    mp.start_processes(_train_worker, args=(2, port + 1, str(tmp_path), scale, steps), nprocs=2, join=True,
-                       start_method='spawn')
+    port = 29800 + (os.getpid() % 1000) + (7 if aggregate_first else 0)
+    _train_worker(0, 1, port, str(tmp_path), scale, steps, aggregate_first)
+    mp.start_processes(_train_worker, args=(2, port + 1, str(tmp_path), scale, steps, aggregate_first), nprocs=2,
+                       join=True, start_method='spawn')
     l1, l2 = np.load(tmp_path / 'loss_w1.npy'), np.load(tmp_path / 'loss_w2.npy')
     assert np.all(np.isfinite(l1)) and l1[-1] < l1[0]
     assert np.allclose(l1, l2, rtol=1e-5)
@@ -156,9 +159,11 @@ def test_sharded_training_step_matches_single_gpu(tmp_path):
     assert (d <= 1e-5 * np.abs(w1).max()).mean() >= 0.999 and d.max() <= 1e-3 * np.abs(w1).max()
 
 
-def test_sharded_step_against_a_dense_float64_model():
+@pytest.mark.parametrize('aggregate_first', [False, True])
+def test_sharded_step_against_a_dense_float64_model(aggregate_first):
     """The sharded model on one rank, dropout off, against the same 2-layer GCN written with dense
-    float64 torch operations and autograd: loss trajectory over 4 Adam steps."""
+    float64 torch operations and autograd: loss trajectory over 4 Adam steps, for both orders of the
+    first layer's products."""
     from gcn_amd import dist as gdist, sparse
     from gcn_amd.dist_train import ShardedGCN
     scale, f_in, hidden, classes = 10, 24, 16, 5
@@ -172,7 +177,8 @@ def test_sharded_step_against_a_dense_float64_model():
     cls = torch.randint(0, classes, (n,), generator=gen)
     labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32).cuda()
     mask = (torch.rand(n, generator=gen) < 0.2).to(torch.int32).cuda()
-    model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.0, seed=9)
+    model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.0, seed=9,
+                       aggregate_first=aggregate_first)
     # dense float64 twin
     rows = torch.repeat_interleave(torch.arange(n, device='cuda'), indptr[1:] - indptr[:-1])
     a = torch.zeros((n, n), dtype=torch.float64, device='cuda')
