@@ -49,6 +49,19 @@ __device__ __forceinline__ bool keep_entry(uint64_t key, uint64_t idx, float kee
     return floorf(__fadd_rn(keep_prob, uniform24(key, idx))) >= 1.0f;
 }
 
+// Dropout applied to the OUTPUT of a product -- sparse x dense or dense x dense -- (the next layer's
+// tf.nn.dropout on its input, gcn/layers.py:185, fused into the store): element (r, col) of C draws decision
+// index_offset + r * pitch + col of stream `key` -- the decision a separate pass over a matrix
+// `pitch` columns wide would draw, of which C may be a row block and a column range.
+struct OutDrop {
+    uint64_t key;
+    float keep_prob;     // 1: off
+    int64_t index_offset;
+    int64_t pitch;
+    const uint64_t* stream_offset;  // device value added to stream_id when the kernel runs (HIP-graph replays); may be null
+    uint64_t seed, stream_id;
+};
+
 // Fixed bijection on [0, 2^bits): odd multiplications and xor-shifts, each invertible modulo 2^bits.
 // The R-MAT generator relabels vertices with it so that hub vertices are spread over the id range.
 __host__ __device__ __forceinline__ uint64_t scramble_id(uint64_t v, int bits, uint64_t key) {

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
                                                            float* __restrict__ c, int64_t ldc, int relu, int a_vec,
                                                            int b_vec, int64_t tiles_m, int64_t tiles_n,
                                                            const float* __restrict__ gate, int64_t ldg,
-                                                           float divisor) {
+                                                           float divisor, OutDrop od) {
     constexpr int kWavesN = (BN >= 64) ? 2 : 1;
     constexpr int kWavesM = 4 / kWavesN;
     constexpr int MT = kBM / (kWavesM * 32);
@@ -386,6 +386,28 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
             }
         return;
     }
+    if (od.keep_prob < 1.0f) {
+        // C = dropout(act(A.B)): the next layer's input dropout in the store (decision id = index_offset +
+        // row * pitch + column, as a separate pass over C would draw it)
+        const uint64_t key = od.stream_offset ? stream_key(od.seed, od.stream_id + *od.stream_offset) : od.key;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int64_t gc = n0 + (wn * NT + j) * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t gr = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (interior || (gr < m && gc < n)) {
+                        float v = acc[i][j][e];
+                        if (relu) v = v > 0.0f ? v : 0.0f;
+                        const uint64_t id = (uint64_t)(od.index_offset + gr * od.pitch + gc);
+                        c[gr * ldc + gc] = keep_entry(key, id, od.keep_prob) ? __fdiv_rn(v, od.keep_prob) : 0.0f;
+                    }
+                }
+            }
+        return;
+    }
     if (interior) {
         // no bounds tests and one running pointer per 32x32 tile: the guarded form below spends ~15
         // VALU instructions per stored element, as much issue time as a tenth of a K = 512 tile's MFMAs
@@ -424,7 +446,8 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
 template <int kBM, int BN>
 static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
                        int trans_b, float* c, int64_t ldc, int relu, hipStream_t st, const float* gate = nullptr,
-                       int64_t ldg = 0, float divisor = 1.0f) {
+                       int64_t ldg = 0, float divisor = 1.0f, const OutDrop* out_drop = nullptr) {
+    const OutDrop od = out_drop ? *out_drop : OutDrop{0, 1.0f, 0, 0, nullptr, 0, 0};
     const int64_t tiles_m = ceil_div(m, kBM), tiles_n = ceil_div(n, BN);
     const int64_t n_tiles = tiles_m * tiles_n;
     if (n_tiles > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
@@ -432,7 +455,7 @@ static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
     const int b_vec = (ldb % 4 == 0) && (((uintptr_t)b & 15) == 0);
 #define GCN_GEMM_GO(TB, BK)                                                                                  \
     gemm_mfma_kernel<kBM, BN, TB, BK><<<(unsigned)n_tiles, kBlock, 0, st>>>(m, n, k, a, lda, b, ldb, c, ldc, relu, a_vec, \
-                                                                       b_vec, tiles_m, tiles_n, gate, ldg, divisor)
+                                                                       b_vec, tiles_m, tiles_n, gate, ldg, divisor, od)
     if (k <= 16) {
         if (trans_b)
             GCN_GEMM_GO(true, 16);
@@ -718,6 +741,27 @@ int gcn_gemm_gated_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
     if (n <= 32) return launch_gemm<128, 32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, 0, st, gate, ldg, divisor);
     if (n <= 64) return launch_gemm<128, 64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, 0, st, gate, ldg, divisor);
     return launch_gemm<128, 128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, 0, st, gate, ldg, divisor);
+}
+
+int gcn_gemm_out_dropout_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                             int trans_b, float* c, int64_t ldc, int flags, float keep_prob, uint64_t seed,
+                             uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
+                             void* stream) {
+    if (m < 0 || n < 0 || k < 0) return fail(GCN_ERR_BAD_ARG, "negative dimension");
+    if (lda < k || ldc < n || ldb < (trans_b ? k : n)) return fail(GCN_ERR_BAD_ARG, "leading dimension too small");
+    if (flags & ~GCN_RELU) return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
+    if (index_offset < 0 || pitch < n)
+        return fail(GCN_ERR_BAD_ARG, "bad decision layout: index_offset=%lld pitch=%lld for %lld columns",
+                    (long long)index_offset, (long long)pitch, (long long)n);
+    if (m == 0 || n == 0) return GCN_OK;
+    if (!c || (k > 0 && (!a || !b))) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int relu = (flags & GCN_RELU) ? 1 : 0;
+    const OutDrop od = {stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset, seed, stream_id};
+    if (n <= 32) return launch_gemm<128, 32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st, nullptr, 0, 1.0f, &od);
+    if (n <= 64) return launch_gemm<128, 64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st, nullptr, 0, 1.0f, &od);
+    return launch_gemm<128, 128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st, nullptr, 0, 1.0f, &od);
 }
 
 int gcn_gemm_tn_workspace_bytes(int64_t m, int64_t n, int64_t k, size_t* bytes) {

@@ -156,19 +156,6 @@ struct DropArgs {
     uint64_t seed, stream_id;
 };
 
-// Dropout applied to the product's OUTPUT (the next layer's tf.nn.dropout on its input,
-// gcn/layers.py:185, fused into the store): element (r, col) of C draws decision
-// index_offset + r * pitch + col of stream `key` -- the decision a separate pass over a matrix
-// `pitch` columns wide would draw, of which C may be a row block and a column range.
-struct OutDrop {
-    uint64_t key;
-    float keep_prob;     // 1: off
-    int64_t index_offset;
-    int64_t pitch;
-    const uint64_t* stream_offset;  // as in DropArgs
-    uint64_t seed, stream_id;
-};
-
 // sparse_dropout decisions of one batch of U entries starting at kb, for a lane group of LPR lanes.
 // Every lane of a group needs all U decisions, but a decision costs a 64-bit hash: lane `sub` of the
 // group hashes only entries sub, sub + LPR, ... and a wave ballot hands the bits round.

@@ -73,11 +73,10 @@ class _AggregatedFirstLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, s, w, relu, out_dropout):
-        z = sparse.gemm(s, w, relu=relu)
+        # out_dropout: the next layer's input dropout, in this product's store; its backward is the
+        # consumer's (_GatedGemmFn)
+        z = sparse.gemm(s, w, relu=relu, out_dropout=out_dropout)
         ctx.gate = relu and out_dropout is None
-        if out_dropout is not None:        # the next layer's input dropout; its backward is the consumer's (_GatedGemmFn)
-            d = out_dropout
-            z = sparse.dropout(z, d.keep_prob, d.seed, d.stream_id, index_offset=d.index_offset)
         if ctx.gate:
             ctx.save_for_backward(s, z)
         else:

@@ -437,8 +437,9 @@ def dropout(x, keep_prob, seed, stream_id, gate=None, index_offset=0):
     return y
 
 
-def gemm(a, b, trans_b=False, relu=False, out=None):
-    """``a @ b`` (or ``a @ b.T``) in float32 on the MFMA pipe."""
+def gemm(a, b, trans_b=False, relu=False, out=None, out_dropout=None):
+    """``a @ b`` (or ``a @ b.T``) in float32 on the MFMA pipe.  ``out_dropout`` (an OutDropout): the result
+    is written already dropped, after the ReLU."""
     _require_cuda(a, b)
     a, b = _rowmajor(a), _rowmajor(b)
     m, k = a.shape
@@ -450,6 +451,12 @@ def gemm(a, b, trans_b=False, relu=False, out=None):
     else:
         _check_out(out, m, n)
         c = out
+    if out_dropout is not None and out_dropout.keep_prob < 1.0:
+        d = out_dropout
+        _lib.call('gcn_gemm_out_dropout_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), 1 if trans_b else 0, _p(c), _ld(c),
+                  _lib.GCN_RELU if relu else 0, d.keep_prob, d.seed, d.stream_id, _p(_stream_offset), d.index_offset,
+                  n if d.pitch is None else int(d.pitch), _stream())
+        return c
     _lib.call('gcn_gemm_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), 1 if trans_b else 0, _p(c), _ld(c),
               _lib.GCN_RELU if relu else 0, _stream())
     return c

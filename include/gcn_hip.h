@@ -234,6 +234,15 @@ int gcn_gemm_gated_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
                        int trans_b, const float* gate, int64_t ldg, float divisor, float* c, int64_t ldc,
                        void* stream);
 
+/* C = dropout(act(A . op(B))): tf.matmul (gcn/layers.py:32-33) with the activation and the NEXT layer's
+ * tf.nn.dropout on its input (gcn/layers.py:185) in the store -- the dense counterpart of
+ * gcn_spmm_csr_out_dropout_f32, with the same decision ids (index_offset + r * pitch + c) and the same
+ * bits as gcn_gemm_f32 followed by gcn_dropout_f32. */
+int gcn_gemm_out_dropout_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                             int trans_b, float* c, int64_t ldc, int flags, float keep_prob, uint64_t seed,
+                             uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
+                             void* stream);
+
 /* C[k x n] = A^T . G for A [m x k] and G [m x n], both row-major: the weight gradient
  * dW = H^T . dP that tf.train.AdamOptimizer.minimize derives for tf.matmul and for
  * tf.sparse_tensor_dense_matmul with a dense left operand (gcn/models.py:86, gcn/layers.py:28-34).

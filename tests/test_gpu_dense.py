@@ -145,3 +145,25 @@ def test_gated_product_equals_product_then_gate(oracle, m, n, k, trans_b):
     sparse.gemm_gated(a, bt, gate, 0.5, trans_b=trans_b, out=wide[:, 2:2 + n])
     assert torch.equal(wide[:, 2:2 + n], torch.where(gate > 0, plain / torch.full_like(plain, 0.5), torch.zeros_like(plain)))
     assert bool((wide[:, :2] == 2.0).all()) and bool((wide[:, 2 + n:] == 2.0).all())
+
+
+@pytest.mark.parametrize('m,n,k', [(5000, 256, 64), (1000, 130, 33), (129, 33, 2), (4096, 16, 256)])
+@pytest.mark.parametrize('trans_b', [False, True])
+def test_product_with_dropout_in_its_store(oracle, m, n, k, trans_b):
+    """dropout(relu(A . B)) written by the GEMM: the bits of the product followed by the oracle's dense
+    dropout with the same decision ids (a row block of a taller matrix, a column range of a wider one)."""
+    import torch
+    from gcn_amd import sparse
+    a = _t(oracle.synthetic_dense(m, k, seed=81))
+    b = oracle.synthetic_dense(k, n, seed=82)
+    bt = _t(np.ascontiguousarray(b.T)) if trans_b else _t(b)
+    plain = sparse.gemm(a, bt, trans_b=trans_b, relu=True)
+    row0 = 333
+    od = sparse.OutDropout(0.5, 17, 9, index_offset=row0 * n)
+    fused = sparse.gemm(a, bt, trans_b=trans_b, relu=True, out_dropout=od)
+    ref, _ = oracle.dense_dropout(plain.cpu().numpy(), 0.5, oracle.stream_key(17, 9), index_offset=row0 * n)
+    assert np.array_equal(fused.cpu().numpy(), ref)
+    wide = torch.full((m, n + 8), -2.0, device='cuda')
+    sparse.gemm(a, bt, trans_b=trans_b, relu=True, out=wide[:, 4:4 + n],
+                out_dropout=sparse.OutDropout(0.5, 17, 9, index_offset=row0 * n))
+    assert torch.equal(wide[:, 4:4 + n], fused) and bool((wide[:, :4] == -2.0).all()) and bool((wide[:, 4 + n:] == -2.0).all())
