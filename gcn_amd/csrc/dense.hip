@@ -390,6 +390,27 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
         // C = dropout(act(A.B)): the next layer's input dropout in the store (decision id = index_offset +
         // row * pitch + column, as a separate pass over C would draw it)
         const uint64_t key = od.stream_offset ? stream_key(od.seed, od.stream_id + *od.stream_offset) : od.key;
+        if (interior) {     // running pointer and running decision id, no bounds tests
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int64_t r0 = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);
+                    const int64_t c0 = n0 + (wn * NT + j) * 32 + l31;
+                    float* cp = c + r0 * ldc + c0;
+                    uint64_t id = (uint64_t)(od.index_offset + r0 * od.pitch + c0);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[i][j][e];
+                        if (relu) v = v > 0.0f ? v : 0.0f;
+                        cp[0] = keep_entry(key, id, od.keep_prob) ? __fdiv_rn(v, od.keep_prob) : 0.0f;
+                        const int step = ((e & 3) == 3) ? 5 : 1;
+                        cp += step * ldc;
+                        id += (uint64_t)(step * od.pitch);
+                    }
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -398,7 +419,7 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t gr = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (interior || (gr < m && gc < n)) {
+                    if (gr < m && gc < n) {
                         float v = acc[i][j][e];
                         if (relu) v = v > 0.0f ? v : 0.0f;
                         const uint64_t id = (uint64_t)(od.index_offset + gr * od.pitch + gc);
