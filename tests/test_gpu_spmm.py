@@ -51,6 +51,22 @@ def test_hat_times_dense_bit_exact(graph_fx, oracle, f):
     assert np.array_equal(out_relu, np.maximum(ref, 0))
 
 
+def test_hat_times_dense_equals_the_committed_known_answers(graph_fx, oracle):
+    """The HIP product against vectors committed with the repository (scipy's float32 CSR product = the
+    serial loop of the reference's CPU kernel, oracle/make_known_answers.py), bit for bit."""
+    from conftest import load_golden
+    from gcn_amd import sparse
+    name, fx = graph_fx
+    known = load_golden('spmm_known_answers')
+    n, ip, ix, v = _hat(fx)
+    a = _device_csr(n, n, ip, ix, v)
+    for key in known.files:
+        if key.startswith(name + '_f'):
+            f = int(key.split('_f')[1].split('_')[0])
+            b = oracle.synthetic_dense(n, f, seed=int(known['seed']))
+            assert np.array_equal(sparse.spmm(a, _t(b)).cpu().numpy(), known[key])
+
+
 def test_the_triple_order_of_the_reference_gives_the_same_sums(graph_fx, oracle):
     """The literal nnz loop over the (column-major) triple of preprocess_adj equals the CSR row loop."""
     name, fx = graph_fx

@@ -75,6 +75,22 @@ def test_serial_spmm_forms_agree(graph_fx, oracle):
         assert np.abs(c - c64).max() <= 1e-6 * np.abs(c64).max()
 
 
+def test_oracle_reproduces_the_committed_known_answers(graph_fx, oracle):
+    """A_hat . B for seeded B, as scipy's float32 CSR product (the serial loop of the reference's CPU
+    kernel) computed it when the vectors were committed (oracle/make_known_answers.py): the C loop gives
+    the same bits today."""
+    name, fx = graph_fx
+    known = load_golden('spmm_known_answers')
+    n = int(fx['n'])
+    ip, ix, v32, _ = oracle.triple_to_csr(fx['hat_indices'], fx['hat_values'], fx['hat_shape'])
+    widths = [int(k.split('_f')[1].split('_')[0]) for k in known.files if k.startswith(name + '_f') and k.endswith('_f32')]
+    assert len(widths) >= 1
+    for f in widths:
+        b = oracle.synthetic_dense(n, f, seed=int(known['seed']))
+        c = oracle.spmm_csr(ip, ix, v32, b)
+        assert np.array_equal(c, known['%s_f%d_f32' % (name, f)])
+
+
 def test_feature_triple_order(dataset_fx, oracle):
     """sparse_to_tuple(features) (train.py:118): row-grouped, order inside a row as stored."""
     name, fx = dataset_fx
