@@ -76,6 +76,23 @@ class RowShardedCSR(object):
         return cls(n_rows, n_cols, r0, r1, local, rank, world)
 
 
+def shard_with_columns(shard, col_keep):
+    """The shard restricted to the columns flagged in ``col_keep`` (bool, one flag per global column),
+    entry order inside every row unchanged.  When the unflagged rows of the dense operand are zero --
+    the gradient of the logits of a semi-supervised model is zero outside the labelled nodes -- a
+    product with this matrix adds the same nonzero terms in the same order as the product with the
+    whole shard: the same bits on every row that product sums serially (hub rows, which it sums in
+    chunks, agree to rounding)."""
+    local = shard.local
+    keep = col_keep[local.indices.to(torch.int64)]
+    before = torch.zeros(local.nnz + 1, dtype=torch.int64, device=keep.device)
+    torch.cumsum(keep, dim=0, out=before[1:])
+    kept = type(local)(local.n_rows, local.n_cols, before[local.indptr].contiguous(), local.indices[keep].contiguous(),
+                       local.values[keep].contiguous())
+    return RowShardedCSR(shard.n_rows_global, shard.n_cols, shard.row_begin, shard.row_end, kept, shard.rank,
+                         shard.world)
+
+
 class AllGatherSpmm(object):
     """C_local = A_local . all_gather(B_local), buffers allocated once."""
 

@@ -11,7 +11,8 @@ import numpy as np
 import torch
 
 from . import graph, sparse
-from .dist import HaloPlan, all_reduce_sum, column_chunks, column_shares, halo_product
+from .dist import (HaloPlan, all_gather_rows, all_reduce_sum, column_chunks, column_shares, halo_product,
+                   shard_with_columns)
 from .layers import _GatedGemmFn, _GemmFn
 from .models import TfAdam
 
@@ -31,12 +32,14 @@ def _product(plan, b_local, relu, chunks, out_dropout=None):
 
 class _HaloSpmmFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, b_local, fuse_relu, chunks, gate_here, out_dropout=None):
+    def forward(ctx, plan, b_local, fuse_relu, chunks, gate_here, out_dropout=None, backward_plan=None):
         """``gate_here`` False: the backward of the ReLU (and of ``out_dropout``, the next layer's input
         dropout applied in this product's store) is applied by whoever consumes this output -- the
-        gradient that arrives here is already the one of the pre-activation."""
+        gradient that arrives here is already the one of the pre-activation.
+        ``backward_plan``: the plan of the backward product when the arriving gradient is known to be zero
+        outside some rows (the support restricted to those columns: fewer entries, a smaller exchange)."""
         out = _product(plan, b_local, fuse_relu, chunks, out_dropout)
-        ctx.plan, ctx.gate, ctx.chunks = plan, fuse_relu and gate_here, chunks
+        ctx.plan, ctx.gate, ctx.chunks = backward_plan or plan, fuse_relu and gate_here, chunks
         if ctx.gate:
             ctx.save_for_backward(out)
         return out
@@ -48,7 +51,7 @@ class _HaloSpmmFn(torch.autograd.Function):
             grad = sparse.dropout(grad, 1.0, 0, 0, gate=out)
         plan = ctx.plan
         # symmetric support: rows of A^T are rows of A
-        return None, _product(plan, grad.contiguous(), False, ctx.chunks), None, None, None, None
+        return None, _product(plan, grad.contiguous(), False, ctx.chunks), None, None, None, None, None
 
 
 class _ShardDropoutFn(torch.autograd.Function):
@@ -119,6 +122,7 @@ class ShardedGCN(object):
             self.weights.append(w.requires_grad_(True))
         self.optimizer = TfAdam(self.weights, learning_rate)
         self._mask_cache = {}
+        self._grad_plans = {}
         self.step_count = 0
 
     def _all_reduce(self, t):
@@ -126,7 +130,26 @@ class ShardedGCN(object):
             all_reduce_sum(t, group=self.group)
         return t
 
-    def forward(self, x_local, train):
+    def _logit_gradient_plan(self, mask_local):
+        """The plan of the last layer's backward product A^T . d logits.  The gradient of the masked loss
+        is zero at every node outside the mask (gcn/metrics.py:85-92), so only the columns of labelled
+        nodes contribute: the support is restricted to them once per mask (1/64 of the entries for one
+        labelled node in 64) and the exchange shrinks with it.  The same terms in the same order as the
+        product with the whole support."""
+        hit = self._grad_plans.get(id(mask_local))
+        if hit is None or hit[0] is not mask_local:
+            flags = (mask_local != 0).to(torch.int32)
+            if self.shard.world > 1:
+                everyone = torch.empty(self.shard.n_cols, dtype=torch.int32, device=flags.device)
+                all_gather_rows(everyone, flags.contiguous(), group=self.group)
+            else:
+                everyone = flags
+            plan = HaloPlan(shard_with_columns(self.shard, everyone != 0), group=self.group)
+            hit = (mask_local, plan)
+            self._grad_plans[id(mask_local)] = hit
+        return hit[1]
+
+    def forward(self, x_local, train, logit_gradient_plan=None):
         """Dropout on every layer's input (gcn/models.py:60): a pass over the features for the first
         layer; for the others it is applied in the store of the product that makes the input, and its
         backward (with the ReLU's) in the store of the product that makes the input's gradient."""
@@ -150,7 +173,8 @@ class ShardedGCN(object):
                 offset = self.shard.row_begin * h.shape[1]
                 h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64, offset)
             p = _GatedGemmFn.apply(h, w, keep) if drop and li > 0 else _GemmFn.apply(h, w)
-            h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop)
+            h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop,
+                                  logit_gradient_plan if li == last else None)
         return h
 
     def _local_mask_mean(self, mask_local):
@@ -173,7 +197,7 @@ class ShardedGCN(object):
         self.step_count += 1
         mask_mean = self._local_mask_mean(mask_local)
         with torch.enable_grad():
-            logits = self.forward(x_local, train=True)
+            logits = self.forward(x_local, train=True, logit_gradient_plan=self._logit_gradient_plan(mask_local))
             stats, dlogits = sparse.softmax_xent(logits.detach(), labels_local, mask_local, mask_mean)
             grads = torch.autograd.grad(logits, self.weights, grad_outputs=dlogits)
         flat = torch.cat([g.reshape(-1) for g in grads] + [stats[:, 0].mean().reshape(1)])

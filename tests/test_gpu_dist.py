@@ -202,3 +202,29 @@ def test_sharded_step_against_a_dense_float64_model(aggregate_first):
                 mm += 0.1 * (g - mm)
                 vv += 0.001 * (g * g - vv)
                 p -= lr_t * mm / (vv.sqrt() + 1e-8)
+
+
+def test_support_restricted_to_labelled_columns_gives_the_same_bits():
+    """A . G for a G that is zero outside the labelled rows, with the whole support and with the support
+    cut down to the labelled columns (the last layer's backward product): 1/16 of the entries, identical
+    bits on every row the full product sums serially, 1e-5 on the chunked hub rows."""
+    from gcn_amd import dist as gdist, sparse
+    scale = 14
+    n = 1 << scale
+    indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, 1)
+    labelled = (torch.arange(n, device='cuda') % 16 == 3)
+    g = sparse.synthetic_dense(n, 7, seed=3) * labelled[:, None]
+    cut = gdist.shard_with_columns(shard, labelled)
+    assert 0 < cut.local.nnz < shard.local.nnz // 8
+    full = sparse.spmm(shard.local, g)
+    part = sparse.spmm(cut.local, g)
+    # rows the full product sums serially: the same terms in the same order, the zeros left out
+    serial = (indptr[1:] - indptr[:-1]) <= shard.local.plan.split_nnz
+    assert int((~serial).sum()) > 0 and torch.equal(part[serial], full[serial])
+    # hub rows are summed in chunks by the full product and (shorter now) serially by the cut one
+    assert float((part - full).abs().max()) <= 1e-5 * float(full.abs().max())
+    plan = gdist.HaloPlan(cut)
+    assert torch.equal(gdist.halo_product(plan, g, torch.empty_like(full)), part)
