@@ -93,6 +93,22 @@ def shard_with_columns(shard, col_keep):
                          shard.world)
 
 
+def shard_with_rows(shard, row_keep):
+    """The shard with the entries of unflagged local rows removed (those rows become empty; ``row_keep``:
+    bool, one flag per local row).  The product with it gives the flagged rows of the full product, bit
+    for bit, and zeros elsewhere: the rows of the logits a masked loss reads (gcn/metrics.py:85-92)."""
+    local = shard.local
+    counts = local.indptr[1:] - local.indptr[:-1]
+    kept_counts = counts * row_keep.to(counts.dtype)
+    keep = torch.repeat_interleave(row_keep, counts)
+    indptr = torch.zeros(local.n_rows + 1, dtype=torch.int64, device=counts.device)
+    torch.cumsum(kept_counts, dim=0, out=indptr[1:])
+    kept = type(local)(local.n_rows, local.n_cols, indptr, local.indices[keep].contiguous(),
+                       local.values[keep].contiguous())
+    return RowShardedCSR(shard.n_rows_global, shard.n_cols, shard.row_begin, shard.row_end, kept, shard.rank,
+                         shard.world)
+
+
 class AllGatherSpmm(object):
     """C_local = A_local . all_gather(B_local), buffers allocated once."""
 

@@ -12,7 +12,7 @@ import torch
 
 from . import graph, sparse
 from .dist import (HaloPlan, all_gather_rows, all_reduce_sum, column_chunks, column_shares, halo_product,
-                   shard_with_columns)
+                   shard_with_columns, shard_with_rows)
 from .layers import _GatedGemmFn, _GemmFn
 from .models import TfAdam
 
@@ -130,8 +130,12 @@ class ShardedGCN(object):
             all_reduce_sum(t, group=self.group)
         return t
 
-    def _logit_gradient_plan(self, mask_local):
-        """The plan of the last layer's backward product A^T . d logits.  The gradient of the masked loss
+    def _logit_plans(self, mask_local):
+        """(forward, backward) plans of the last layer's products in a training step.
+
+        Forward: the masked loss reads the logits of labelled nodes only, so only their rows of
+        A . (H' . W) are computed (the other rows of the support are emptied; their logits come out as 0
+        and weigh 0 in the loss).  Backward: A^T . d logits.  The gradient of the masked loss
         is zero at every node outside the mask (gcn/metrics.py:85-92), so only the columns of labelled
         nodes contribute: the support is restricted to them once per mask (1/64 of the entries for one
         labelled node in 64) and the exchange shrinks with it.  The same terms in the same order as the
@@ -144,12 +148,13 @@ class ShardedGCN(object):
                 all_gather_rows(everyone, flags.contiguous(), group=self.group)
             else:
                 everyone = flags
-            plan = HaloPlan(shard_with_columns(self.shard, everyone != 0), group=self.group)
-            hit = (mask_local, plan)
+            backward = HaloPlan(shard_with_columns(self.shard, everyone != 0), group=self.group)
+            forward = HaloPlan(shard_with_rows(self.shard, flags != 0), group=self.group)
+            hit = (mask_local, (forward, backward))
             self._grad_plans[id(mask_local)] = hit
         return hit[1]
 
-    def forward(self, x_local, train, logit_gradient_plan=None):
+    def forward(self, x_local, train, logit_plans=None):
         """Dropout on every layer's input (gcn/models.py:60): a pass over the features for the first
         layer; for the others it is applied in the store of the product that makes the input, and its
         backward (with the ReLU's) in the store of the product that makes the input's gradient."""
@@ -173,8 +178,10 @@ class ShardedGCN(object):
                 offset = self.shard.row_begin * h.shape[1]
                 h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64, offset)
             p = _GatedGemmFn.apply(h, w, keep) if drop and li > 0 else _GemmFn.apply(h, w)
-            h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop,
-                                  logit_gradient_plan if li == last else None)
+            if li == last and logit_plans is not None:     # a training step: labelled rows forward, labelled columns backward
+                h = _HaloSpmmFn.apply(logit_plans[0], p, False, self.chunks, not drop, None, logit_plans[1])
+            else:
+                h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop)
         return h
 
     def _local_mask_mean(self, mask_local):
@@ -197,7 +204,7 @@ class ShardedGCN(object):
         self.step_count += 1
         mask_mean = self._local_mask_mean(mask_local)
         with torch.enable_grad():
-            logits = self.forward(x_local, train=True, logit_gradient_plan=self._logit_gradient_plan(mask_local))
+            logits = self.forward(x_local, train=True, logit_plans=self._logit_plans(mask_local))
             stats, dlogits = sparse.softmax_xent(logits.detach(), labels_local, mask_local, mask_mean)
             grads = torch.autograd.grad(logits, self.weights, grad_outputs=dlogits)
         flat = torch.cat([g.reshape(-1) for g in grads] + [stats[:, 0].mean().reshape(1)])
