@@ -142,8 +142,10 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, cl
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = float(t.item())
     return {'ms': ms, 'loss': float(loss), 'layers': [int(x_local.shape[1]), hidden, classes], 'steps': steps,
-            'what': 'forward + backward + Adam, dropout 0.5, rows/%d; first layer as %s' % (
-                group_world, "(A.X').W0: no backward product" if model.aggregate_first else "A.(X'.W0)")}
+            'what': 'forward + backward + Adam, dropout 0.5, one labelled node in 64, rows/%d; first layer as %s%s' % (
+                group_world, "(A.X').W0: no backward product" if model.aggregate_first else "A.(X'.W0)",
+                '; hidden rows formed only where a labelled node reads them'
+                if (model.receptive_field and model.aggregate_first) else '')}
 
 
 def cpu_baseline(a, b_dev, c_dev, row_stride):

@@ -61,7 +61,7 @@ SIGNATURES = {
     'gcn_spmm_csr_out_dropout_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64, _vp,
                                      _i64, _i64, _vp, _sz, _vp],
     'gcn_gemm_out_dropout_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _f32, _u64, _u64, _vp,
-                                 _i64, _i64, _vp],
+                                 _i64, _i64, _vp, _vp],
     'gcn_gemm_gated_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64, _f32, _vp, _i64, _vp],
     'gcn_row_normalize': [_i64, _i64, _vp, _vp, _int, _vp, _vp],
     'gcn_dropout_f32': [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _f32, _u64, _u64, _vp, _u64, _vp],

@@ -60,6 +60,9 @@ struct OutDrop {
     int64_t pitch;
     const uint64_t* stream_offset;  // device value added to stream_id when the kernel runs (HIP-graph replays); may be null
     uint64_t seed, stream_id;
+    // dense products only, may be null: row r of C is row row_ids[r] of the matrix the decisions are drawn
+    // for (C holds a subset of its rows)
+    const int64_t* row_ids;
 };
 
 // Fixed bijection on [0, 2^bits): odd multiplications and xor-shifts, each invertible modulo 2^bits.

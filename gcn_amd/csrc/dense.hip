@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
         // C = dropout(act(A.B)): the next layer's input dropout in the store (decision id = index_offset +
         // row * pitch + column, as a separate pass over C would draw it)
         const uint64_t key = od.stream_offset ? stream_key(od.seed, od.stream_id + *od.stream_offset) : od.key;
-        if (interior) {     // running pointer and running decision id, no bounds tests
+        if (interior && !od.row_ids) {     // running pointer and running decision id, no bounds tests
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -422,7 +422,8 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
                     if (gr < m && gc < n) {
                         float v = acc[i][j][e];
                         if (relu) v = v > 0.0f ? v : 0.0f;
-                        const uint64_t id = (uint64_t)(od.index_offset + gr * od.pitch + gc);
+                        const int64_t drawn_row = od.row_ids ? od.row_ids[gr] : gr;
+                        const uint64_t id = (uint64_t)(od.index_offset + drawn_row * od.pitch + gc);
                         c[gr * ldc + gc] = keep_entry(key, id, od.keep_prob) ? __fdiv_rn(v, od.keep_prob) : 0.0f;
                     }
                 }
@@ -767,7 +768,7 @@ int gcn_gemm_gated_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
 int gcn_gemm_out_dropout_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
                              int trans_b, float* c, int64_t ldc, int flags, float keep_prob, uint64_t seed,
                              uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
-                             void* stream) {
+                             const int64_t* row_ids, void* stream) {
     if (m < 0 || n < 0 || k < 0) return fail(GCN_ERR_BAD_ARG, "negative dimension");
     if (lda < k || ldc < n || ldb < (trans_b ? k : n)) return fail(GCN_ERR_BAD_ARG, "leading dimension too small");
     if (flags & ~GCN_RELU) return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
@@ -779,7 +780,8 @@ int gcn_gemm_out_dropout_f32(int64_t m, int64_t n, int64_t k, const float* a, in
     if (!c || (k > 0 && (!a || !b))) return fail(GCN_ERR_BAD_ARG, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int relu = (flags & GCN_RELU) ? 1 : 0;
-    const OutDrop od = {stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset, seed, stream_id};
+    const OutDrop od = {stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset, seed, stream_id,
+                        row_ids};
     if (n <= 32) return launch_gemm<128, 32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st, nullptr, 0, 1.0f, &od);
     if (n <= 64) return launch_gemm<128, 64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st, nullptr, 0, 1.0f, &od);
     return launch_gemm<128, 128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st, nullptr, 0, 1.0f, &od);

@@ -109,6 +109,22 @@ def shard_with_rows(shard, row_keep):
                          shard.world)
 
 
+def shard_rows_compacted(shard, rows):
+    """The rows ``rows`` (ascending local row numbers, int64) of the shard as a matrix of their own:
+    row i of the result is local row rows[i], columns and entry order unchanged."""
+    local = shard.local
+    counts = (local.indptr[1:] - local.indptr[:-1])
+    flag = torch.zeros(local.n_rows, dtype=torch.bool, device=rows.device)
+    flag[rows] = True
+    keep = torch.repeat_interleave(flag, counts)
+    indptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=rows.device)
+    torch.cumsum(counts[rows], dim=0, out=indptr[1:])
+    kept = type(local)(int(rows.numel()), local.n_cols, indptr, local.indices[keep].contiguous(),
+                       local.values[keep].contiguous())
+    return RowShardedCSR(shard.n_rows_global, shard.n_cols, shard.row_begin, shard.row_end, kept, shard.rank,
+                         shard.world)
+
+
 class AllGatherSpmm(object):
     """C_local = A_local . all_gather(B_local), buffers allocated once."""
 
@@ -139,7 +155,10 @@ class HaloPlan(object):
     references a fraction of the columns (72 / 52 / 37 % at 2 / 4 / 8 ranks on the scale-24 R-MAT) and
     the exchange moves that fraction of what an all-gather moves."""
 
-    def __init__(self, shard, group=None, csr_factory=None):
+    def __init__(self, shard, group=None, csr_factory=None, operand_rows=None):
+        """``operand_rows`` (ascending local row numbers, int64): the dense operand every rank passes to
+        ``exchange`` holds only these rows of its block, in this order (every requested row must be among
+        them)."""
         self.shard, self.group = shard, group
         local = shard.local
         dev = local.device
@@ -148,8 +167,8 @@ class HaloPlan(object):
         if shard.n_cols % world != 0:
             raise ValueError('n_cols=%d is not a multiple of the world size %d' % (shard.n_cols, world))
         self._collective = world > 1 or (dist.is_initialized() and dist.get_world_size(group) == 1)
-        if not self._collective and shard.n_cols == local.n_rows:
-            # one process, no communicator: the shard is the matrix and B is its own operand
+        if not self._collective and operand_rows is None:
+            # one process, no communicator: the operand holds every column's row, B is its own halo
             self.compact, self.n_needed, self._identity, self._buffers = local, shard.n_cols, True, {}
             self.recv_splits = self.send_splits = [shard.n_cols]
             return
@@ -173,10 +192,16 @@ class HaloPlan(object):
             all_to_all_rows(self.send_rows, request, self.send_splits, self.recv_splits, group=group)
         else:
             self.send_rows.copy_(request)
+        if operand_rows is not None:                                 # row numbers -> positions in the operand
+            position = torch.full((per,), -1, dtype=torch.int64, device=dev)
+            position[operand_rows] = torch.arange(operand_rows.numel(), dtype=torch.int64, device=dev)
+            self.send_rows = position[self.send_rows]
+            if self.send_rows.numel() and int(self.send_rows.min()) < 0:
+                raise ValueError('a requested row is not among operand_rows')
         make = csr_factory or sparse.DeviceCSR
         self.compact = make(local.n_rows, int(needed.numel()), local.indptr, new_cols, local.values)
         self.n_needed = int(needed.numel())
-        self._identity = (not self._collective) and self.n_needed == shard.n_cols == local.n_rows
+        self._identity = False
         self._buffers = {}
 
     def drop_buffers(self, keep_widths=()):

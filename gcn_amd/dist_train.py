@@ -12,7 +12,7 @@ import torch
 
 from . import graph, sparse
 from .dist import (HaloPlan, all_gather_rows, all_reduce_sum, column_chunks, column_shares, halo_product,
-                   shard_with_columns, shard_with_rows)
+                   shard_rows_compacted, shard_with_columns, shard_with_rows)
 from .layers import _GatedGemmFn, _GemmFn
 from .models import TfAdam
 
@@ -104,7 +104,7 @@ class ShardedGCN(object):
     backward product of that layer (see _AggregatedFirstLayerFn)."""
 
     def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
-                 seed=0, group=None, chunks=4, aggregate_first=None):
+                 seed=0, group=None, chunks=4, aggregate_first=None, receptive_field=True):
         self.shard, self.group = shard, group
         # ranges of feature columns an exchange is pipelined over: a count, or a tuple of width shares
         self.chunks = chunks if shard.world > 1 else 1
@@ -112,6 +112,8 @@ class ShardedGCN(object):
         self.dropout, self.wd, self.seed = float(dropout), float(weight_decay), int(seed)
         sizes = [f_in] + list(layer_size) + [n_classes]
         self.aggregate_first = (f_in <= sizes[1]) if aggregate_first is None else bool(aggregate_first)
+        # a training step of a two-layer model forms only the hidden rows the labelled nodes read
+        self.receptive_field = bool(receptive_field)
         dev = shard.local.device
         g = torch.Generator(device=dev)
         g.manual_seed(self.seed)                       # every rank draws the same replicated weights
@@ -153,6 +155,59 @@ class ShardedGCN(object):
             hit = (mask_local, (forward, backward))
             self._grad_plans[id(mask_local)] = hit
         return hit[1]
+
+    def _receptive_plans(self, mask_local):
+        """Plans of a training step of a two-layer model cut down to what the masked loss can see.
+
+        The loss reads the logits of labelled nodes; those read the hidden rows of their neighbours (the
+        set R, one node in eight on the scale-24 R-MAT with one label in 64) and nothing else, so the
+        hidden layer is computed for R only: S = A[R, :] . X', H = act(S . W0), P = H' . W1 are matrices of
+        |R| rows, the logits are A[labelled, R] . P and the backward product is A[R, labelled] . d logits.
+        Every number that reaches the loss or a weight gradient is the one the full computation produces
+        (dropout decisions are drawn by global row); rows outside R are never formed."""
+        hit = self._grad_plans.get(('receptive', id(mask_local)))
+        if hit is None or hit[0] is not mask_local:
+            dev = mask_local.device
+            flags = (mask_local != 0)
+            labelled_rows = shard_with_rows(self.shard, flags)
+            seen = torch.zeros(self.shard.n_cols, dtype=torch.float32, device=dev)
+            seen[labelled_rows.local.indices.to(torch.int64)] = 1.0
+            self._all_reduce(seen)                                   # columns some rank's labelled rows reference
+            r_local = torch.nonzero(seen[self.shard.row_begin:self.shard.row_end] > 0).reshape(-1)
+            del seen
+            if self.shard.world > 1:
+                everyone = torch.empty(self.shard.n_cols, dtype=torch.int32, device=dev)
+                all_gather_rows(everyone, flags.to(torch.int32).contiguous(), group=self.group)
+                everyone = everyone != 0
+            else:
+                everyone = flags
+            plans = {
+                'rows': r_local,
+                'row_ids': (r_local + self.shard.row_begin).contiguous(),
+                'wide': HaloPlan(shard_rows_compacted(self.shard, r_local), group=self.group),
+                'logits': HaloPlan(labelled_rows, group=self.group, operand_rows=r_local),
+                'back': HaloPlan(shard_rows_compacted(shard_with_columns(self.shard, everyone), r_local),
+                                 group=self.group),
+            }
+            hit = (mask_local, plans)
+            self._grad_plans[('receptive', id(mask_local))] = hit
+        return hit[1]
+
+    def _forward_receptive(self, x_local, plans):
+        keep = 1.0 - self.dropout
+        drop = keep < 1.0
+        w0, w1 = self.weights
+        h = x_local
+        if drop:                                                     # the input has no gradient: a plain pass
+            h = sparse.dropout(h, keep, self.seed, self.step_count * 64,
+                               index_offset=self.shard.row_begin * h.shape[1])
+        s = _product(plans['wide'], h, False, self.chunks)
+        next_drop = None
+        if drop:
+            next_drop = sparse.OutDropout(keep, self.seed, self.step_count * 64 + 1, 0, w0.shape[1], plans['row_ids'])
+        h = _AggregatedFirstLayerFn.apply(s, w0, True, next_drop)
+        p = _GatedGemmFn.apply(h, w1, keep) if drop else _GemmFn.apply(h, w1)
+        return _HaloSpmmFn.apply(plans['logits'], p, False, self.chunks, True, None, plans['back'])
 
     def forward(self, x_local, train, logit_plans=None):
         """Dropout on every layer's input (gcn/models.py:60): a pass over the features for the first
@@ -204,7 +259,10 @@ class ShardedGCN(object):
         self.step_count += 1
         mask_mean = self._local_mask_mean(mask_local)
         with torch.enable_grad():
-            logits = self.forward(x_local, train=True, logit_plans=self._logit_plans(mask_local))
+            if self.receptive_field and self.aggregate_first and len(self.weights) == 2:
+                logits = self._forward_receptive(x_local, self._receptive_plans(mask_local))
+            else:
+                logits = self.forward(x_local, train=True, logit_plans=self._logit_plans(mask_local))
             stats, dlogits = sparse.softmax_xent(logits.detach(), labels_local, mask_local, mask_mean)
             grads = torch.autograd.grad(logits, self.weights, grad_outputs=dlogits)
         flat = torch.cat([g.reshape(-1) for g in grads] + [stats[:, 0].mean().reshape(1)])

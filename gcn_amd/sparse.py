@@ -319,13 +319,15 @@ class OutDropout(object):
     stream (seed, stream_id): the one ``dropout`` draws for a matrix ``pitch`` columns wide of which
     the output is a row block (index_offset = first row * pitch) and possibly a column range."""
 
-    def __init__(self, keep_prob, seed, stream_id, index_offset=0, pitch=None):
+    def __init__(self, keep_prob, seed, stream_id, index_offset=0, pitch=None, row_ids=None):
+        """``row_ids`` (int64 device tensor, dense products only): the output holds a subset of the rows of
+        that matrix, and its row r draws the decisions of row ``row_ids[r]``."""
         self.keep_prob, self.seed, self.stream_id = float(keep_prob), int(seed), int(stream_id)
-        self.index_offset, self.pitch = int(index_offset), pitch
+        self.index_offset, self.pitch, self.row_ids = int(index_offset), pitch, row_ids
 
     def columns(self, c0):
         """The same decisions for the column range that starts at column ``c0``."""
-        return OutDropout(self.keep_prob, self.seed, self.stream_id, self.index_offset + c0, self.pitch)
+        return OutDropout(self.keep_prob, self.seed, self.stream_id, self.index_offset + c0, self.pitch, self.row_ids)
 
 
 def spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None):
@@ -346,6 +348,8 @@ def spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None):
     flags = (_lib.GCN_RELU if relu else 0) | (_lib.GCN_SPLIT_WIDE if wide_split else 0)
     if out_dropout is not None and out_dropout.keep_prob < 1.0:
         d = out_dropout
+        if d.row_ids is not None:
+            raise ValueError('row_ids apply to dense products only')
         _lib.call('gcn_spmm_csr_out_dropout_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(b),
                   _ld(b), _p(out), _ld(out), flags, d.keep_prob, d.seed, d.stream_id, _p(_stream_offset),
                   d.index_offset, f if d.pitch is None else int(d.pitch), _p(ws), ws_bytes, _stream())
@@ -453,9 +457,11 @@ def gemm(a, b, trans_b=False, relu=False, out=None, out_dropout=None):
         c = out
     if out_dropout is not None and out_dropout.keep_prob < 1.0:
         d = out_dropout
+        if d.row_ids is not None and (d.row_ids.dtype != torch.int64 or d.row_ids.numel() != m or not d.row_ids.is_cuda):
+            raise ValueError('row_ids must be an int64 device tensor with one entry per output row')
         _lib.call('gcn_gemm_out_dropout_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), 1 if trans_b else 0, _p(c), _ld(c),
                   _lib.GCN_RELU if relu else 0, d.keep_prob, d.seed, d.stream_id, _p(_stream_offset), d.index_offset,
-                  n if d.pitch is None else int(d.pitch), _stream())
+                  n if d.pitch is None else int(d.pitch), _p(d.row_ids), _stream())
         return c
     _lib.call('gcn_gemm_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), 1 if trans_b else 0, _p(c), _ld(c),
               _lib.GCN_RELU if relu else 0, _stream())

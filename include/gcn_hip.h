@@ -237,11 +237,12 @@ int gcn_gemm_gated_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
 /* C = dropout(act(A . op(B))): tf.matmul (gcn/layers.py:32-33) with the activation and the NEXT layer's
  * tf.nn.dropout on its input (gcn/layers.py:185) in the store -- the dense counterpart of
  * gcn_spmm_csr_out_dropout_f32, with the same decision ids (index_offset + r * pitch + c) and the same
- * bits as gcn_gemm_f32 followed by gcn_dropout_f32. */
+ * bits as gcn_gemm_f32 followed by gcn_dropout_f32.  row_ids (may be NULL): C holds a subset of the rows
+ * of the matrix the decisions are drawn for, and row r of C draws the decisions of row row_ids[r]. */
 int gcn_gemm_out_dropout_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
                              int trans_b, float* c, int64_t ldc, int flags, float keep_prob, uint64_t seed,
                              uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
-                             void* stream);
+                             const int64_t* row_ids, void* stream);
 
 /* C[k x n] = A^T . G for A [m x k] and G [m x n], both row-major: the weight gradient
  * dW = H^T . dP that tf.train.AdamOptimizer.minimize derives for tf.matmul and for

@@ -167,3 +167,17 @@ def test_product_with_dropout_in_its_store(oracle, m, n, k, trans_b):
     sparse.gemm(a, bt, trans_b=trans_b, relu=True, out=wide[:, 4:4 + n],
                 out_dropout=sparse.OutDropout(0.5, 17, 9, index_offset=row0 * n))
     assert torch.equal(wide[:, 4:4 + n], fused) and bool((wide[:, :4] == -2.0).all()) and bool((wide[:, 4 + n:] == -2.0).all())
+
+
+def test_dropout_store_of_a_row_subset_draws_the_rows_own_decisions(oracle):
+    """A GEMM over a subset of the rows of A, with the row map: every output row carries the decisions
+    that row has in the product over all rows."""
+    import torch
+    from gcn_amd import sparse
+    m, n, k = 3000, 256, 64
+    a = _t(oracle.synthetic_dense(m, k, seed=91))
+    b = _t(oracle.synthetic_dense(k, n, seed=92))
+    full = sparse.gemm(a, b, relu=True, out_dropout=sparse.OutDropout(0.5, 5, 6))
+    rows = torch.sort(torch.randperm(m, generator=torch.Generator().manual_seed(1))[:1111])[0].cuda()
+    part = sparse.gemm(a[rows].contiguous(), b, relu=True, out_dropout=sparse.OutDropout(0.5, 5, 6, pitch=n, row_ids=rows))
+    assert torch.equal(part, full[rows])

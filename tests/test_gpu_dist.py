@@ -228,3 +228,34 @@ def test_support_restricted_to_labelled_columns_gives_the_same_bits():
     assert float((part - full).abs().max()) <= 1e-5 * float(full.abs().max())
     plan = gdist.HaloPlan(cut)
     assert torch.equal(gdist.halo_product(plan, g, torch.empty_like(full)), part)
+
+
+def test_receptive_field_step_equals_the_full_step():
+    """Training steps that form only the hidden rows the labelled nodes read against steps that form all
+    of them: the same dropout decisions (drawn by global row), the same loss, the same weights."""
+    from gcn_amd import dist as gdist, sparse
+    from gcn_amd.dist_train import ShardedGCN
+    scale, f_in, hidden, classes = 14, 32, 64, 8
+    n = 1 << scale
+    indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, 1)
+    x = sparse.synthetic_dense(n, f_in, seed=7)
+    gen = torch.Generator().manual_seed(5)
+    labels = torch.nn.functional.one_hot(torch.randint(0, classes, (n,), generator=gen), classes).to(torch.int32).cuda()
+    mask = (torch.arange(n) % 64 == 5).to(torch.int32).cuda()
+    runs = []
+    for receptive in (False, True):
+        model = ShardedGCN(shard, f_in, [hidden], classes, dropout=0.5, seed=9, aggregate_first=True,
+                           receptive_field=receptive)
+        losses = [float(model.train_step(x, labels, mask)) for _ in range(4)]
+        runs.append((losses, [w.detach().clone() for w in model.weights]))
+        if receptive:
+            rows = model._receptive_plans(mask)['rows']
+            assert 0 < rows.numel() < n // 2                      # a fraction of the hidden rows was formed
+    (l0, w0), (l1, w1) = runs
+    assert np.allclose(l0, l1, rtol=1e-6) and l0[-1] < l0[0]
+    for a, b in zip(w0, w1):        # Adam divides by sqrt(v): entries whose gradient is nearly zero amplify rounding
+        d, top = (a - b).abs(), float(a.abs().max())
+        assert float((d <= 1e-5 * top).float().mean()) >= 0.999 and float(d.max()) <= 1e-3 * top
