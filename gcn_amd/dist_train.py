@@ -162,7 +162,8 @@ class ShardedGCN(object):
         The loss reads the logits of labelled nodes; those read the hidden rows of their neighbours (the
         set R, one node in eight on the scale-24 R-MAT with one label in 64) and nothing else, so the
         hidden layer is computed for R only: S = A[R, :] . X', H = act(S . W0), P = H' . W1 are matrices of
-        |R| rows, the logits are A[labelled, R] . P and the backward product is A[R, labelled] . d logits.
+        |R| rows, the logits are A[labelled, R] . P -- one row per labelled node -- and the backward product
+        is A[R, labelled] . d logits.
         Every number that reaches the loss or a weight gradient is the one the full computation produces
         (dropout decisions are drawn by global row); rows outside R are never formed."""
         hit = self._grad_plans.get(('receptive', id(mask_local)))
@@ -181,13 +182,15 @@ class ShardedGCN(object):
                 everyone = everyone != 0
             else:
                 everyone = flags
+            lab_rows = torch.nonzero(flags).reshape(-1)              # the logits are formed for these rows only
             plans = {
                 'rows': r_local,
                 'row_ids': (r_local + self.shard.row_begin).contiguous(),
+                'labelled': lab_rows,
                 'wide': HaloPlan(shard_rows_compacted(self.shard, r_local), group=self.group),
-                'logits': HaloPlan(labelled_rows, group=self.group, operand_rows=r_local),
+                'logits': HaloPlan(shard_rows_compacted(self.shard, lab_rows), group=self.group, operand_rows=r_local),
                 'back': HaloPlan(shard_rows_compacted(shard_with_columns(self.shard, everyone), r_local),
-                                 group=self.group),
+                                 group=self.group, operand_rows=lab_rows),
             }
             hit = (mask_local, plans)
             self._grad_plans[('receptive', id(mask_local))] = hit
@@ -260,12 +263,29 @@ class ShardedGCN(object):
         mask_mean = self._local_mask_mean(mask_local)
         with torch.enable_grad():
             if self.receptive_field and self.aggregate_first and len(self.weights) == 2:
-                logits = self._forward_receptive(x_local, self._receptive_plans(mask_local))
+                plans = self._receptive_plans(mask_local)
+                logits = self._forward_receptive(x_local, plans)          # one row per labelled local node
+                rows = plans['labelled']
+                key = ('labels', id(labels_local))
+                hit = self._mask_cache.get(key)
+                if hit is None or hit[0] is not labels_local:
+                    hit = (labels_local, labels_local[rows].contiguous(),
+                           torch.ones(rows.numel(), dtype=torch.int32, device=rows.device))
+                    self._mask_cache[key] = hit
+                if rows.numel():
+                    # every labelled row weighs 1 / (global number of labelled nodes): the loss kernel divides
+                    # by the rows it is given and by mask_mean
+                    count_global = mask_mean * mask_local.numel()
+                    stats, dlogits = sparse.softmax_xent(logits.detach(), hit[1], hit[2], count_global / rows.numel())
+                    local_loss = stats[:, 0].mean().reshape(1)
+                else:                                                     # a rank without labelled nodes
+                    dlogits, local_loss = torch.zeros_like(logits), torch.zeros(1, device=logits.device)
             else:
                 logits = self.forward(x_local, train=True, logit_plans=self._logit_plans(mask_local))
-            stats, dlogits = sparse.softmax_xent(logits.detach(), labels_local, mask_local, mask_mean)
+                stats, dlogits = sparse.softmax_xent(logits.detach(), labels_local, mask_local, mask_mean)
+                local_loss = stats[:, 0].mean().reshape(1)
             grads = torch.autograd.grad(logits, self.weights, grad_outputs=dlogits)
-        flat = torch.cat([g.reshape(-1) for g in grads] + [stats[:, 0].mean().reshape(1)])
+        flat = torch.cat([g.reshape(-1) for g in grads] + [local_loss])
         self._all_reduce(flat)
         with torch.no_grad():
             reg = sum(self.wd * (w * w).sum() / 2 for w in self.weights)       # with the weights of this forward
