@@ -256,9 +256,9 @@ class ShardedGCN(object):
     def train_step(self, x_local, labels_local, mask_local):
         """One optimiser step; returns the global loss (data term + weight decay) as a 0-d tensor.
         Loss, accuracy rows and d loss / d logits come from one kernel over the local logits
-        (gcn/metrics.py:85-92 with the mask normalised globally); the weight gradients and the loss are
-        summed over the ranks in one all-reduce; Adam and the weight-decay term run in one kernel per
-        variable."""
+        (gcn/metrics.py:85-92 with the mask normalised globally) -- over the labelled nodes' logits alone
+        when the step runs on their receptive field; the weight gradients and the loss are summed over the
+        ranks in one all-reduce; Adam and the weight-decay term run in one kernel per variable."""
         self.step_count += 1
         mask_mean = self._local_mask_mean(mask_local)
         with torch.enable_grad():
