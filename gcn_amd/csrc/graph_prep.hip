@@ -365,6 +365,46 @@ __global__ void fill_synthetic_kernel(int64_t count, uint64_t key, float* __rest
     }
 }
 
+// bit 0: a row index outside [0, n_rows); bit 1: a column index outside [0, n_cols)
+__global__ void check_coo_kernel(int64_t nnz, const int32_t* __restrict__ rows, int64_t n_rows,
+                                 const int32_t* __restrict__ cols, int64_t n_cols, int* __restrict__ bad) {
+    int mine = 0;
+    GCN_GRID_STRIDE(k, nnz) {
+        if (rows) {
+            const int64_t r = rows[k];
+            if (r < 0 || r >= n_rows) mine |= 1;
+        }
+        if (cols) {
+            const int64_t c = cols[k];
+            if (c < 0 || c >= n_cols) mine |= 2;
+        }
+    }
+    if (mine) atomicOr(bad, mine);
+}
+
+// Range check of a COO index pair before any kernel uses an index as an address: the reference raises
+// ValueError (scipy's coo_matrix) or InvalidArgumentError (TensorFlow's per-nonzero check) for the same
+// inputs.  Waits for the stream.
+static int check_coo_range(int64_t nnz, const int32_t* rows, int64_t n_rows, const int32_t* cols, int64_t n_cols,
+                           hipStream_t st) {
+    if (nnz == 0) return GCN_OK;
+    int* flag = nullptr;
+    GCN_HIP_TRY(hipMalloc(&flag, sizeof(int)));
+    int host = 0;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
+    if (e == hipSuccess) {
+        check_coo_kernel<<<grid_for(nnz), kBlock, 0, st>>>(nnz, rows, n_rows, cols, n_cols, flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(flag);
+    if (e != hipSuccess) return fail(GCN_ERR_HIP, "index check failed: %s", hipGetErrorString(e));
+    if (host & 1) return fail(GCN_ERR_INDEX_RANGE, "a row index is outside [0, %lld)", (long long)n_rows);
+    if (host & 2) return fail(GCN_ERR_INDEX_RANGE, "a column index is outside [0, %lld)", (long long)n_cols);
+    return GCN_OK;
+}
+
 }  // namespace gcn
 
 using namespace gcn;
@@ -398,6 +438,10 @@ int gcn_coo_to_csr(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const int32_t
     SortScratch s;
     int rc = carve_scratch(workspace, workspace_bytes, m, valued, &s);
     if (rc != GCN_OK) return rc;
+    // the keys pack each index into 32 bits and the scatter walks indptr by row: nothing below is safe
+    // for an index outside the shape
+    rc = check_coo_range(nnz_in, rows, n_rows, cols, n_cols, st);
+    if (rc != GCN_OK) return rc;
     if (m > 0) {
         pack_coo_keys_kernel<<<grid_for(m), kBlock, 0, st>>>(nnz_in, n_loops, rows, cols, vals, s.keys_a,
                                                              valued ? s.vals_a : nullptr);
@@ -415,6 +459,8 @@ int gcn_rows_to_indptr(int64_t n_rows, int64_t nnz, const int32_t* rows, int64_t
         GCN_HIP_TRY(hipMemsetAsync(indptr_out, 0, (size_t)(n_rows + 1) * 8, st));
         return GCN_OK;
     }
+    const int rc = check_coo_range(nnz, rows, n_rows, nullptr, 0, st);
+    if (rc != GCN_OK) return rc;
     rows_to_indptr_kernel<<<grid_for(nnz), kBlock, 0, st>>>(n_rows, nnz, rows, indptr_out);
     GCN_LAUNCH_CHECK();
     return GCN_OK;

@@ -255,6 +255,8 @@ class ShardedGCN(object):
 
     def train_step(self, x_local, labels_local, mask_local):
         """One optimiser step; returns the global loss (data term + weight decay) as a 0-d tensor.
+        Plans, mask counts and gathered labels are cached per (labels, mask) tensor OBJECT: pass a new
+        tensor for a new label set or mask -- a tensor changed in place keeps its cached plans.
         Loss, accuracy rows and d loss / d logits come from one kernel over the local logits
         (gcn/metrics.py:85-92 with the mask normalised globally) -- over the labelled nodes' logits alone
         when the step runs on their receptive field; the weight gradients and the loss are summed over the
@@ -266,11 +268,12 @@ class ShardedGCN(object):
                 plans = self._receptive_plans(mask_local)
                 logits = self._forward_receptive(x_local, plans)          # one row per labelled local node
                 rows = plans['labelled']
-                key = ('labels', id(labels_local))
+                # the gathered labels belong to the pair (labels, mask): the rows come from the mask
+                key = ('labels', id(labels_local), id(mask_local))
                 hit = self._mask_cache.get(key)
-                if hit is None or hit[0] is not labels_local:
+                if hit is None or hit[0] is not labels_local or hit[3] is not mask_local:
                     hit = (labels_local, labels_local[rows].contiguous(),
-                           torch.ones(rows.numel(), dtype=torch.int32, device=rows.device))
+                           torch.ones(rows.numel(), dtype=torch.int32, device=rows.device), mask_local)
                     self._mask_cache[key] = hit
                 if rows.numel():
                     # every labelled row weighs 1 / (global number of labelled nodes): the loss kernel divides

@@ -130,7 +130,12 @@ class GCN_MLP(object):
 
     # ------------------------------------------------------------------ #
     def _bind(self, feed_dict):
-        """Put the fed values behind the placeholders, uploading each host object once."""
+        """Put the fed values behind the placeholders, uploading each host object once.
+
+        The device copy of a fed host array or triple is cached by object identity: feeding the same
+        object again (as train.py does every epoch) costs nothing, and a value CHANGED IN PLACE after its
+        first feed is not seen -- feed a new array (``mask.copy()``) instead.  The reference path of this
+        build never mutates a fed value; its label-expansion code (gcn/utils.py:554) does."""
         for ph in list(self.placeholders.values()):
             for p in (ph if isinstance(ph, (list, tuple)) else [ph]):
                 if isinstance(p, graph.Placeholder):

@@ -63,14 +63,17 @@ int gcn_coo_to_csr_bound(int64_t n_rows, int64_t nnz_in, int flags, int64_t* nnz
  * and `sp.coo_matrix(adj)` at gcn/utils.py:300,321.
  * vals may be NULL (all ones).  vals_out (float64) may be NULL with GCN_BINARY.
  * indices_out / vals_out must hold nnz_capacity entries; *nnz_out (device
- * int64) receives the merged count. */
+ * int64) receives the merged count.  A row or column index outside the shape is
+ * GCN_ERR_INDEX_RANGE (scipy's coo_matrix raises ValueError for it) and nothing
+ * is written.  [sync] */
 int gcn_coo_to_csr(int64_t n_rows, int64_t n_cols, int64_t nnz_in, const int32_t* rows, const int32_t* cols,
                    const double* vals, int flags, int64_t* indptr_out, int32_t* indices_out, double* vals_out,
                    int64_t* nnz_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* indptr from a non-decreasing row array: CSR view of a row-grouped triple
  * that keeps the triple's own order inside every row (the feature triple of
- * sparse_to_tuple, gcn/utils.py:258-275 as fed at train.py:118). */
+ * sparse_to_tuple, gcn/utils.py:258-275 as fed at train.py:118).  A row index
+ * outside [0, n_rows) is GCN_ERR_INDEX_RANGE.  [sync] */
 int gcn_rows_to_indptr(int64_t n_rows, int64_t nnz, const int32_t* rows, int64_t* indptr_out, void* stream);
 
 /* rowsum = adj.sum(1) (gcn/utils.py:301, 310).  vals NULL = all ones. float64 out. */

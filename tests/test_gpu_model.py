@@ -261,3 +261,64 @@ def test_test_accuracy_over_seeds_matches_the_oracle(name, oracle):
     assert abs(gpu_acc.mean() - ref_acc.mean()) <= sigma, (gpu_acc, ref_acc)
     assert np.abs(gpu_acc - ref_acc).max() <= 0.02, (gpu_acc, ref_acc)
     assert ref_acc.mean() > (0.70 if name == 'cora' else 0.58)
+
+
+@pytest.mark.parametrize('dense_input', [False, True])
+def test_pubmed_two_layer_logits_at_fixed_weights(oracle, dense_input):
+    """PubMed (19,717 nodes, 3 classes): A_hat from the reference's own preprocess_adj (fixture), X a
+    seeded synthetic 19,717 x 500 matrix -- the dataset's feature file is absent upstream -- fed either
+    as a sparse triple (entries above 0.8 kept: ~50 per row, like the real bag of words) or as a dense
+    placeholder; fixed Glorot weights, dropout 0 (gcn/models.py:54-69).
+    Criterion: max|gpu - ref64| <= 1e-5 * max|ref64| against a float64 evaluation of the same model."""
+    import scipy.sparse as sp
+    from gcn_amd import graph as tf
+    from gcn_amd.models import GCN_MLP
+    from gcn_amd.utils import SupportValue, construct_feed_dict
+    fx = load_golden('pubmed_graph')
+    n, f_in, classes = int(fx['n']), 500, 3
+    x = oracle.synthetic_dense(n, f_in, seed=19)
+    if not dense_input:
+        x = np.where(x > 0.8, x, np.float32(0))
+    support = [SupportValue(fx['hat_indices'], fx['hat_values'], fx['hat_shape'])]
+    rng = np.random.RandomState(8)
+    labels = np.eye(classes)[rng.randint(0, classes, n)]
+    mask = np.zeros(n, dtype=bool)
+    mask[rng.choice(n, 60, replace=False)] = True
+    tf.set_random_seed(41)
+    if dense_input:
+        features = x
+        feat_ph = tf.placeholder(tf.float32, shape=(None, f_in), name='features')
+    else:
+        r, c = np.nonzero(x)                                   # row-major, columns ascending
+        features = SupportValue(np.stack([r, c], 1).astype(np.int32), x[r, c], np.array([n, f_in], dtype=np.int64))
+        feat_ph = tf.sparse_placeholder(tf.float32, name='features')
+        assert 40 < r.size / n < 60
+    placeholders = {
+        'support': [tf.sparse_placeholder(tf.float32, name='support0')],
+        'features': feat_ph,
+        'labels': tf.placeholder(tf.int32, name='labels', shape=(None, classes)),
+        'labels_mask': tf.placeholder(tf.int32, name='labels_mask'),
+        'dropout': tf.placeholder_with_default(0., name='dropout', shape=()),
+        'num_features_nonzero': tf.placeholder(tf.int32, name='num_features_nonzero'),
+    }
+    cfg = {'name': 'gcn', 'connection': ['c', 'c'], 'layer_size': [16], 'conv': 'gcn', 'learning_rate': 0.02,
+           'weight_decay': 5e-4, 'Model': 'GCN', 'dropout': 0.5}
+    model = GCN_MLP(cfg, placeholders, input_dim=f_in)
+    if dense_input:
+        feed = {placeholders['labels']: labels, placeholders['labels_mask']: mask, placeholders['features']: x,
+                placeholders['support'][0]: support[0], placeholders['num_features_nonzero']: (0,)}
+    else:
+        feed = construct_feed_dict(features, support, labels, mask, placeholders)
+    outputs, loss, acc = tf.Session().run([model.outputs, model.loss, model.accuracy], feed_dict=feed)
+    # float64 evaluation with the float32 values the placeholders hold (train.py:145-146)
+    w0, w1 = (w.detach().cpu().numpy().astype(np.float64) for w in model._trainable())
+    a = sp.csr_matrix((fx['hat_values'].astype(np.float32).astype(np.float64),
+                       (fx['hat_indices'][:, 0], fx['hat_indices'][:, 1])), shape=(n, n))
+    h = np.maximum(a @ (x.astype(np.float64) @ w0), 0)
+    ref64 = a @ (h @ w1)
+    assert outputs.shape == (n, classes)
+    assert np.abs(outputs - ref64).max() <= REL_TOL * np.abs(ref64).max()
+    ref_loss = 5e-4 * ((w0 ** 2).sum() + (w1 ** 2).sum()) / 2 \
+        + float(oracle.GcnOracle.masked_softmax_cross_entropy(ref64, labels, mask))      # gcn/models.py:92-99
+    assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert abs(float(acc) - float(oracle.GcnOracle.masked_accuracy(ref64, labels, mask))) <= 1e-6

@@ -201,3 +201,46 @@ def test_synthetic_dense_matches_oracle(oracle):
     ref = oracle.synthetic_dense(1000, 37, seed=7)
     assert np.array_equal(x.cpu().numpy(), ref)
     assert ref.min() >= -1.0 and ref.max() < 1.0
+
+
+def test_out_of_range_coo_indices_are_rejected_before_any_write():
+    """A row or column index outside the shape (-1, n_rows, n_cols) is a ValueError, as scipy's coo_matrix
+    and TensorFlow's sparse kernels make it, and the output buffers are left as they were."""
+    import ctypes
+    import torch
+    from gcn_amd import _lib, sparse
+    n = 6
+    good_r = torch.tensor([0, 1, 2, 5], dtype=torch.int32, device='cuda')
+    good_c = torch.tensor([1, 0, 3, 5], dtype=torch.int32, device='cuda')
+    for bad_r, bad_c in ([-1, 0], [n, 0], [0, -1], [0, n], [2 ** 31 - 1, 0]):
+        r = torch.cat([good_r, torch.tensor([bad_r], dtype=torch.int32, device='cuda')])
+        c = torch.cat([good_c, torch.tensor([bad_c], dtype=torch.int32, device='cuda')])
+        with pytest.raises(ValueError, match='outside'):
+            sparse.coo_to_csr(n, n, r, c, add_self_loops=True)
+        with pytest.raises(ValueError, match='outside'):
+            sparse.coo_to_csr(n, n, r, c, binary=True)
+    # through the C ABI with sentinel-filled outputs: nothing is written
+    r = torch.tensor([0, 1, n], dtype=torch.int32, device='cuda')
+    c = torch.tensor([0, 1, 2], dtype=torch.int32, device='cuda')
+    cap, ws_bytes = ctypes.c_int64(), ctypes.c_size_t()
+    _lib.call('gcn_coo_to_csr_bound', n, 3, _lib.GCN_BINARY, ctypes.byref(cap), ctypes.byref(ws_bytes))
+    indptr = torch.full((n + 1 + 64,), -7, dtype=torch.int64, device='cuda')
+    indices = torch.full((cap.value + 64,), -7, dtype=torch.int32, device='cuda')
+    nnz_out = torch.full((1,), -7, dtype=torch.int64, device='cuda')
+    ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device='cuda')
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    status = _lib.load().gcn_coo_to_csr(n, n, 3, r.data_ptr(), c.data_ptr(), None, _lib.GCN_BINARY, indptr.data_ptr(),
+                                        indices.data_ptr(), None, nnz_out.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+    torch.cuda.synchronize()
+    assert status == _lib.GCN_ERR_INDEX_RANGE
+    assert bool((indptr == -7).all()) and bool((indices == -7).all()) and int(nnz_out) == -7
+    # gcn_rows_to_indptr: the same check on its row array
+    out = torch.full((n + 1 + 64,), -7, dtype=torch.int64, device='cuda')
+    for rows in ([0, 1, n], [-1, 0, 1]):
+        rr = torch.tensor(rows, dtype=torch.int32, device='cuda')
+        status = _lib.load().gcn_rows_to_indptr(n, 3, rr.data_ptr(), out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert status == _lib.GCN_ERR_INDEX_RANGE and bool((out == -7).all())
+    # the valid part still converts
+    ip, ix, _ = sparse.coo_to_csr(n, n, good_r, good_c, binary=True)
+    assert ip.cpu().tolist() == [0, 1, 2, 3, 3, 3, 4] and ix.cpu().tolist() == [1, 0, 3, 5]
