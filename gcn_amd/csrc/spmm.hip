@@ -17,6 +17,7 @@
 // a separate multiply and add (this file is compiled with -ffp-contract=off): bit-identical to the
 // serial CPU loop.
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -41,7 +42,35 @@ struct gcn_spmm_plan {
     hipEvent_t ev[3];     // start, after the row kernel, after the long-row reduction
 };
 
+// Scratch of gcn_spmm_csr_f32_noalloc: the partial rows of long-row chunks, which the other entry
+// points take from a caller workspace.  One copy per GPU the library runs on, held until the process
+// ends.  In host code the array's name is only a handle for hipGetSymbolAddress: kernels and memory
+// calls get the per-device address that call returns, never the name.
+constexpr size_t kScratchBytes = (size_t)32 << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
 namespace gcn {
+
+constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];   // device address of `scratch` on each GPU, resolved once
+static std::mutex g_scratch_mutex;
+
+// The address of `scratch` on the CURRENT device (each GPU holds its own copy at its own address).
+// Resolved at set-up -- plan creation calls this on the plan's device -- and cached.
+static int scratch_on_current_device(void** out) {
+    int dev = -1;
+    GCN_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(GCN_ERR_BAD_ARG, "device ordinal %d is not supported", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        GCN_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(GCN_ERR_HIP, "hipGetSymbolAddress returned a null address for the scratch array");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return GCN_OK;
+}
 
 constexpr int kStripNnz = 256;       // entries per strip on a matrix large enough to fill the chip with such strips
 constexpr int kStripNnzMin = 16;
@@ -924,6 +953,14 @@ int gcn_spmm_plan_create_split(int64_t n_rows, int64_t n_cols, int64_t nnz, cons
         }                                                                                                    \
     } while (0)
     PLAN_TRY(hipGetDevice(&p->device));
+    {   // set-up of the no-allocation entry point on this device
+        void* unused = nullptr;
+        rc = scratch_on_current_device(&unused);
+        if (rc != GCN_OK) {
+            gcn_spmm_plan_destroy(p);
+            return rc;
+        }
+    }
     PLAN_TRY(hipMalloc(&p->strip_row, (size_t)(p->n_strips + 1) * sizeof(int32_t)));
     strip_rows_kernel<<<(unsigned)ceil_div(p->n_strips + 1, kBlock), kBlock, 0, st>>>(
         n_rows, indptr, p->n_strips, p->strip_nnz, p->strip_row);
@@ -1049,6 +1086,32 @@ int gcn_spmm_csr_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int
                      size_t workspace_bytes, void* stream) {
     DropArgs dr = {nullptr, 0, 1.0f, 1.0f};
     return spmm_entry<false>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
+                             stream);
+}
+
+int gcn_spmm_csr_f32_noalloc(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                             const float* vals, int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc,
+                             int flags, void* stream) {
+    if (!plan) return fail(GCN_ERR_BAD_ARG, "plan is null");
+    if (f < 0) return fail(GCN_ERR_BAD_ARG, "bad width: f=%lld", (long long)f);
+    int dev = -1;
+    GCN_HIP_TRY(hipGetDevice(&dev));
+    if (dev != plan->device)
+        return fail(GCN_ERR_BAD_ARG, "the plan was made on device %d, the current device is %d", plan->device, dev);
+    const int64_t max_chunks = std::max(plan->table[0].n_chunks, plan->table[1].n_chunks);
+    const size_t need = (size_t)max_chunks * (size_t)partial_ld(f) * sizeof(float);
+    if (need > kScratchBytes)
+        return fail(GCN_ERR_WORKSPACE,
+                    "this product needs %zu bytes for the partial rows of its long rows; the no-allocation entry "
+                    "point holds %zu: call gcn_spmm_csr_f32 with a workspace of the caller's",
+                    need, (size_t)kScratchBytes);
+    void* ptr = nullptr;
+    if (need > 0) {
+        const int rc = scratch_on_current_device(&ptr);   // cached by plan creation: a table lookup here
+        if (rc != GCN_OK) return rc;
+    }
+    DropArgs dr = {nullptr, 0, 1.0f, 1.0f};
+    return spmm_entry<false>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, ptr, need ? kScratchBytes : 0, dr,
                              stream);
 }
 

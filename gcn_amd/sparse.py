@@ -359,6 +359,28 @@ def spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None):
     return out
 
 
+NOALLOC_SCRATCH_BYTES = 32 << 20
+
+
+def spmm_noalloc(a, b, out, relu=False):
+    """``a @ b`` into ``out`` through the entry point that allocates nothing: the partial rows of long
+    rows go to the library's own 32 MiB array instead of a workspace (ValueError when the product
+    needs more).  ``b`` and ``out`` must already be row-major float32 device tensors; the plan of ``a``
+    must exist (touch ``a.plan`` beforehand: creating it allocates)."""
+    _require_cuda(b, out)
+    if b.dim() != 2 or b.dtype != torch.float32 or (b.shape[1] > 1 and b.stride(1) != 1):
+        raise ValueError('spmm_noalloc takes a row-major float32 operand as it is')
+    if b.shape[0] != a.n_cols:
+        raise ValueError('shape mismatch: %s @ %s' % (a.shape, tuple(b.shape)))
+    if a._plan is None:
+        raise ValueError('create the plan first (a.plan): plan creation allocates')
+    f = b.shape[1]
+    _check_out(out, a.n_rows, f)
+    _lib.call('gcn_spmm_csr_f32_noalloc', a._plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(b), _ld(b),
+              _p(out), _ld(out), _lib.GCN_RELU if relu else 0, _stream())
+    return out
+
+
 def spmm_add(a, b, d, relu=False, out=None):
     """``a @ b + d`` with the addition fused into the product's epilogue (one smoothing step)."""
     _require_cuda(b, d)

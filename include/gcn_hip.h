@@ -168,6 +168,21 @@ int gcn_spmm_csr_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int
                      int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* gcn_spmm_csr_f32 for callers that cannot allocate or pass a workspace.  It has no counterpart in the
+ * reference; it is for code under HIP graph capture, tight serving loops and harnesses that forbid
+ * hipMalloc.  The partial rows of long rows go to a 32 MiB array inside the library (one per GPU, held
+ * until the process ends) instead of a caller workspace; the call makes no hipMalloc / hipFree and no
+ * allocating library call.  Same kernels, same bits as gcn_spmm_csr_f32.
+ *  - a product whose gcn_spmm_plan_workspace_bytes(plan, f) exceeds 32 MiB is GCN_ERR_WORKSPACE;
+ *  - the plan must have been created on the current device (plan creation resolves the array's
+ *    address there);
+ *  - every call on a GPU shares that GPU's array: two calls that overlap on one GPU (different streams
+ *    or threads) race on it -- order them.  Nothing in it needs to start at zero: a call writes every
+ *    partial row before it reads it. */
+int gcn_spmm_csr_f32_noalloc(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                             const float* vals, int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc,
+                             int flags, void* stream);
+
 /* C = A . B + D: one smoothing / propagation step with the residual added in the epilogue
  * (`new_feature = adj * new_feature + features`, gcn/utils.py:568-569; float32 here).  D is a
  * dense [n_rows x f] matrix; GCN_RELU applies after the addition. */
