@@ -17,6 +17,7 @@ GCN_ERR_WORKSPACE = 4
 
 GCN_ADD_SELF_LOOPS = 1
 GCN_BINARY = 2
+GCN_RMAT_NATURAL_ORDER = 8
 GCN_RELU = 1
 GCN_SPLIT_WIDE = 4
 GCN_NORM_SYM = 0
@@ -43,6 +44,10 @@ SIGNATURES = {
     'gcn_normalize_adj': [_i64, _i64, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp],
     'gcn_csr_transpose_bound': [_i64, _i64, _i64, _psz],
     'gcn_csr_transpose': [_i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    'gcn_degree_order_bound': [_i64, _psz],
+    'gcn_degree_order': [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
+    'gcn_csr_relabel_bound': [_i64, _i64, _int, _psz],
+    'gcn_csr_relabel': [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'gcn_check_indices': [_i64, _vp, _i64, _vp],
     'gcn_rmat_csr_bound': [_int, _int, _int, _pi64, _psz],
     'gcn_rmat_csr': [_int, _int, _u64, _int, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -50,6 +55,7 @@ SIGNATURES = {
     'gcn_spmm_plan_create': [_i64, _i64, _i64, _vp, ctypes.POINTER(_vp), _vp],
     'gcn_spmm_plan_create_split': [_i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_vp), _vp],
     'gcn_spmm_plan_destroy': [_vp],
+    'gcn_spmm_plan_set_hot_columns': [_vp, _i64],
     'gcn_spmm_plan_info': [_vp, _pi64],
     'gcn_spmm_plan_workspace_bytes': [_vp, _i64, _psz],
     'gcn_spmm_plan_set_timing': [_vp, _int],

@@ -322,6 +322,40 @@ static size_t transpose_prim_bytes(int64_t nnz) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// vertex reordering: degree-descending order and relabelling of a CSR structure
+// ------------------------------------------------------------------------------------------------
+// key = (2^32 - 1 - degree) << 32 | vertex: ascending keys = descending degree, ties by ascending id
+__global__ void degree_keys_kernel(int64_t n, const int64_t* __restrict__ indptr, uint64_t* __restrict__ keys) {
+    GCN_GRID_STRIDE(v, n) {
+        const uint64_t deg = (uint64_t)(indptr[v + 1] - indptr[v]);
+        keys[v] = ((0xFFFFFFFFull - deg) << 32) | (uint64_t)v;
+    }
+}
+
+__global__ void order_from_keys_kernel(int64_t n, const uint64_t* __restrict__ sorted, int32_t* __restrict__ new_id,
+                                       int32_t* __restrict__ old_id) {
+    GCN_GRID_STRIDE(i, n) {
+        const uint32_t v = (uint32_t)sorted[i];
+        if (old_id) old_id[i] = (int32_t)v;
+        if (new_id) new_id[v] = (int32_t)i;
+    }
+}
+
+__global__ void relabel_keys_kernel(int64_t n_rows, int64_t nnz, const int64_t* __restrict__ indptr,
+                                    const int32_t* __restrict__ indices, const int32_t* __restrict__ new_row,
+                                    const int32_t* __restrict__ new_col, const double* __restrict__ vals,
+                                    uint64_t* __restrict__ keys, double* __restrict__ kvals) {
+    GCN_GRID_STRIDE(k, nnz) {
+        const int64_t r = row_of_entry(indptr, n_rows, k);
+        const uint32_t c = (uint32_t)indices[k];
+        const uint32_t nr = new_row ? (uint32_t)new_row[r] : (uint32_t)r;
+        const uint32_t nc = new_col ? (uint32_t)new_col[c] : c;
+        keys[k] = ((uint64_t)nr << 32) | nc;
+        if (kvals) kvals[k] = vals[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // index range check
 // ------------------------------------------------------------------------------------------------
 __global__ void check_indices_kernel(int64_t nnz, const int32_t* __restrict__ indices, int64_t n_cols,
@@ -336,7 +370,7 @@ __global__ void check_indices_kernel(int64_t nnz, const int32_t* __restrict__ in
 // R-MAT and synthetic features
 // ------------------------------------------------------------------------------------------------
 __global__ void rmat_keys_kernel(int scale, int64_t n_pairs, int64_t n_loops, uint64_t key, uint64_t label_key,
-                                 uint32_t ta, uint32_t tb, uint32_t tc, uint64_t* __restrict__ keys) {
+                                 int scramble, uint32_t ta, uint32_t tb, uint32_t tc, uint64_t* __restrict__ keys) {
     GCN_GRID_STRIDE(e, n_pairs + n_loops) {
         if (e >= n_pairs) {  // the diagonal of A + I
             const uint64_t d = (uint64_t)(e - n_pairs);
@@ -351,8 +385,10 @@ __global__ void rmat_keys_kernel(int scale, int64_t n_pairs, int64_t n_loops, ui
             v = (v << 1) | (q & 1);
         }
         const bool loop = (u == v);
-        u = scramble_id(u, scale, label_key);
-        v = scramble_id(v, scale, label_key);
+        if (scramble) {
+            u = scramble_id(u, scale, label_key);
+            v = scramble_id(v, scale, label_key);
+        }
         keys[2 * e] = loop ? kInvalidKey : ((u << 32) | v);
         keys[2 * e + 1] = loop ? kInvalidKey : ((v << 32) | u);
     }
@@ -560,6 +596,71 @@ int gcn_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
     return GCN_OK;
 }
 
+int gcn_degree_order_bound(int64_t n_rows, size_t* workspace_bytes) {
+    if (n_rows < 0 || !workspace_bytes) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    *workspace_bytes = sort_scratch_bytes(n_rows, false);
+    return GCN_OK;
+}
+
+int gcn_degree_order(int64_t n_rows, const int64_t* indptr, int32_t* new_id_out, int32_t* old_id_out, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (n_rows < 0 || n_rows > INT32_MAX || !indptr || (!new_id_out && !old_id_out))
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (n_rows == 0) return GCN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    SortScratch s;
+    int rc = carve_scratch(workspace, workspace_bytes, n_rows, false, &s);
+    if (rc != GCN_OK) return rc;
+    degree_keys_kernel<<<grid_for(n_rows), kBlock, 0, st>>>(n_rows, indptr, s.keys_a);
+    GCN_LAUNCH_CHECK();
+    rocprim::double_buffer<uint64_t> kd(s.keys_a, s.keys_b);
+    size_t tb = s.prim_bytes;
+    GCN_HIP_TRY(rocprim::radix_sort_keys(s.prim, tb, kd, (size_t)n_rows, 0u, 64u, st));
+    order_from_keys_kernel<<<grid_for(n_rows), kBlock, 0, st>>>(n_rows, kd.current(), new_id_out, old_id_out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_csr_relabel_bound(int64_t n_rows, int64_t nnz, int valued, size_t* workspace_bytes) {
+    if (n_rows < 0 || nnz < 0 || !workspace_bytes) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    *workspace_bytes = sort_scratch_bytes(nnz, valued != 0);
+    return GCN_OK;
+}
+
+int gcn_csr_relabel(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                    const double* vals, const int32_t* new_row, const int32_t* new_col, int64_t* indptr_out,
+                    int32_t* indices_out, double* vals_out, int64_t* nnz_out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || n_rows > INT32_MAX || n_cols > INT32_MAX || !indptr || !indptr_out ||
+        !nnz_out || (nnz > 0 && (!indices || !indices_out)))
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if ((vals == nullptr) != (vals_out == nullptr)) return fail(GCN_ERR_BAD_ARG, "vals and vals_out go together");
+    hipStream_t st = (hipStream_t)stream;
+    const bool valued = vals != nullptr;
+    SortScratch s;
+    int rc = carve_scratch(workspace, workspace_bytes, nnz, valued, &s);
+    if (rc != GCN_OK) return rc;
+    // the new labels become row numbers and column indices: they must lie inside the shape
+    if (new_row) {
+        rc = check_coo_range(n_rows, new_row, n_rows, nullptr, 0, st);
+        if (rc != GCN_OK) return rc;
+    }
+    if (new_col) {
+        rc = check_coo_range(n_cols, nullptr, 0, new_col, n_cols, st);
+        if (rc != GCN_OK) return rc;
+    }
+    rc = check_coo_range(nnz, nullptr, 0, indices, n_cols, st);
+    if (rc != GCN_OK) return rc;
+    if (nnz > 0) {
+        relabel_keys_kernel<<<grid_for(nnz), kBlock, 0, st>>>(n_rows, nnz, indptr, indices, new_row, new_col, vals,
+                                                             s.keys_a, valued ? s.vals_a : nullptr);
+        GCN_LAUNCH_CHECK();
+    }
+    const unsigned key_bits = 32 + bits_for((uint64_t)(n_rows > 0 ? n_rows - 1 : 0));
+    return sorted_merge_to_csr(&s, nnz, valued, valued ? 0 : 2, key_bits, n_rows, indptr_out, indices_out, vals_out,
+                               nnz_out, st);
+}
+
 int gcn_check_indices(int64_t nnz, const int32_t* indices, int64_t n_cols, void* stream) {
     if (nnz < 0 || (nnz > 0 && !indices)) return fail(GCN_ERR_BAD_ARG, "bad argument");
     if (nnz == 0) return GCN_OK;
@@ -593,7 +694,8 @@ int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int flags, int64_t* 
                  int64_t* nnz_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (scale < 1 || scale > 30 || edge_factor < 1 || !indptr_out || !indices_out || !nnz_out)
         return fail(GCN_ERR_BAD_ARG, "bad argument");
-    if (flags & ~GCN_ADD_SELF_LOOPS) return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    if (flags & ~(GCN_ADD_SELF_LOOPS | GCN_RMAT_NATURAL_ORDER))
+        return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_pairs = (int64_t)edge_factor << scale;
     const int64_t n_loops = (flags & GCN_ADD_SELF_LOOPS) ? ((int64_t)1 << scale) : 0;
@@ -605,7 +707,9 @@ int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int flags, int64_t* 
     const uint32_t tb = (uint32_t)((0.57 + 0.19) * 4294967296.0);
     const uint32_t tc = (uint32_t)((0.57 + 0.19 + 0.19) * 4294967296.0);
     rmat_keys_kernel<<<grid_for(n_pairs + n_loops), kBlock, 0, st>>>(scale, n_pairs, n_loops, stream_key(seed, 0),
-                                                                     stream_key(seed, 1), ta, tb, tc, s.keys_a);
+                                                                     stream_key(seed, 1),
+                                                                     (flags & GCN_RMAT_NATURAL_ORDER) ? 0 : 1, ta, tb,
+                                                                     tc, s.keys_a);
     GCN_LAUNCH_CHECK();
     // invalid keys are all ones and must sort last: sort on all 64 bits
     return sorted_merge_to_csr(&s, m, false, 2, 64u, (int64_t)1 << scale, indptr_out, indices_out, nullptr, nnz_out,

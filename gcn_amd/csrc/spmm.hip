@@ -38,6 +38,9 @@ struct gcn_spmm_plan {
         int64_t* long_chunk;  // [n_long + 1] first chunk of each long row
         int32_t* chunk_long;  // [n_chunks] long-row slot of each chunk
     } table[2];
+    // columns >= hot_cols are loaded with the non-temporal hint by the wave-per-row instances (0: off).
+    // After a degree-descending relabel the first columns are the hub rows of B: the rows worth caching.
+    int64_t hot_cols;
     int timing;           // record events around the kernels of every product
     hipEvent_t ev[3];     // start, after the row kernel, after the long-row reduction
 };
@@ -163,6 +166,22 @@ __device__ __forceinline__ void load_vec<4>(const float* p, float (&out)[4]) {
     out[2] = v.z;
     out[3] = v.w;
 }
+// the same loads with the non-temporal hint (`nt`: the line is marked for early eviction)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ __forceinline__ void load_vec_nt(const float* p, float (&out)[VEC]);
+template <>
+__device__ __forceinline__ void load_vec_nt<1>(const float* p, float (&out)[1]) {
+    out[0] = __builtin_nontemporal_load(p);
+}
+template <>
+__device__ __forceinline__ void load_vec_nt<4>(const float* p, float (&out)[4]) {
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    out[0] = v.x;
+    out[1] = v.y;
+    out[2] = v.z;
+    out[3] = v.w;
+}
 template <int VEC>
 __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]);
 template <>
@@ -223,11 +242,14 @@ __device__ __forceinline__ void drop_decisions(const DropArgs& dr, const DropIds
 // next batch are all in flight together.  Addresses past the end of the range are clamped to its
 // last entry (a valid, cached address) so that no load sits behind a branch; what such a slot
 // loads is never added.
-template <int LPR, int VEC, int VPL, bool DROPOUT>
+// NT (wave-per-row instances only: the column of an entry is the same in every lane): rows of B whose
+// column is >= hot are loaded with the non-temporal hint, so that they do not push the hub rows out of
+// the caches.
+template <int LPR, int VEC, int VPL, bool DROPOUT, bool NT = false>
 __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const int32_t* __restrict__ indices,
                                                  const float* __restrict__ vals, const float* __restrict__ b,
                                                  uint32_t ldb, const int (&lcol)[VPL], const DropArgs& dr,
-                                                 float (&acc)[VPL][VEC]) {
+                                                 float (&acc)[VPL][VEC], uint32_t hot = 0) {
     if (k0 >= k1) return;
     const int64_t k_last = k1 - 1;
     const int sub = (threadIdx.x & 63) % LPR, group_base = (threadIdx.x & 63) - sub;
@@ -246,8 +268,13 @@ __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const i
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const float* brow = b + (uint64_t)c[u] * (uint64_t)ldb;
+            if (NT && (uint32_t)__builtin_amdgcn_readfirstlane((int)c[u]) >= hot) {
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) load_vec<VEC>(brow + lcol[v], bv[u][v]);
+                for (int v = 0; v < VPL; ++v) load_vec_nt<VEC>(brow + lcol[v], bv[u][v]);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) load_vec<VEC>(brow + lcol[v], bv[u][v]);
+            }
         }
         float a_now[kUnroll];
         bool kept[kUnroll];
@@ -377,13 +404,13 @@ __device__ __forceinline__ void store_row(float* dst, const float* addend, const
 }
 
 // rows of ordinary length; one wave per strip
-template <int LPR, int VEC, int VPL, bool DROPOUT, bool PIPED>
+template <int LPR, int VEC, int VPL, bool DROPOUT, bool PIPED, bool NT = false>
 __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, const int32_t* __restrict__ strip_row,
                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                              uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
                                              const DropArgs& dr, int split, const float* __restrict__ add,
-                                             int64_t ldadd, const OutDrop& od) {
+                                             int64_t ldadd, const OutDrop& od, uint32_t hot = 0) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;  // columns covered per pass
     const int lane = threadIdx.x & 63;
@@ -415,7 +442,7 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
             if (PIPED)
                 accumulate_range_piped<LPR, VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
             else
-                accumulate_range<LPR, VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
+                accumulate_range<LPR, VEC, VPL, DROPOUT, NT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc, hot);
             store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
                                 relu != 0, od, r);
         }
@@ -613,14 +640,14 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
 }
 
 // one lane group per chunk of a long row -> partial row in the workspace
-template <int LPR, int VEC, int VPL, bool DROPOUT>
+template <int LPR, int VEC, int VPL, bool DROPOUT, bool NT = false>
 __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, const int32_t* __restrict__ chunk_long,
                                              const int32_t* __restrict__ long_row,
                                              const int64_t* __restrict__ long_chunk,
                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                              uint32_t ldb, float* __restrict__ part, int64_t ldp, const DropArgs& dr,
-                                             int chunk_len) {
+                                             int chunk_len, uint32_t hot = 0) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
@@ -649,7 +676,7 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
         for (int v = 0; v < VPL; ++v)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
-        accumulate_range<LPR, VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
+        accumulate_range<LPR, VEC, VPL, DROPOUT, NT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc, hot);
         const OutDrop none = {0, 1.0f, 0, 0, nullptr, 0, 0};   // partial rows are stored as they are
         store_row<VEC, VPL>(part + chunk * ldp, nullptr, col, on, acc, false, none, 0);
     }
@@ -659,6 +686,7 @@ struct PlanView {
     int64_t n_strips, n_chunks, chunk_blocks, nnz;
     int split;
     int chunk_len;
+    uint32_t hot_cols;
     const int32_t* strip_row;
     const int32_t* chunk_long;
     const int32_t* long_row;
@@ -667,7 +695,7 @@ struct PlanView {
 
 // The whole product in one launch: the blocks that sum chunks of long rows come first (they are
 // the longest work items), the strip blocks after them.
-template <int LPR, int VEC, int VPL, bool DROPOUT, int U>
+template <int LPR, int VEC, int VPL, bool DROPOUT, int U, bool NT = false>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const int64_t* __restrict__ indptr,
                                                            const int32_t* __restrict__ indices,
                                                            const float* __restrict__ vals, int64_t f,
@@ -680,11 +708,12 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
     if (od.keep_prob < 1.0f && od.stream_offset) od.key = stream_key(od.seed, od.stream_id + *od.stream_offset);
     const int64_t block = blockIdx.x;
     if (block < pv.chunk_blocks)
-        chunks_block<LPR, VEC, VPL, DROPOUT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
-                                             indices, vals, f, b, ldb, part, ldp, dr, pv.chunk_len);
+        chunks_block<LPR, VEC, VPL, DROPOUT, NT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
+                                                 indices, vals, f, b, ldb, part, ldp, dr, pv.chunk_len, pv.hot_cols);
     else if (LPR >= 32)
-        strips_block<LPR, VEC, VPL, DROPOUT, (U > kUnroll)>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
-                                             vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd, od);
+        strips_block<LPR, VEC, VPL, DROPOUT, (U > kUnroll), NT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row,
+                                                                indptr, indices, vals, f, b, ldb, c, ldc, relu, dr,
+                                                                pv.split, add, ldadd, od, pv.hot_cols);
     else
         slots_block<LPR, VEC, VPL, DROPOUT, U>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
                                             vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd, pv.nnz, od);
@@ -796,10 +825,22 @@ static int launch_variant(const SpmmCall& a) {
     const int64_t strip_waves = (LPR >= 32) ? p->n_strips : ceil_div(p->n_strips, kGroups);
     const int64_t grid = pv.chunk_blocks + ceil_div(strip_waves, kWaves);
     if (grid > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
+    pv.hot_cols = 0;
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[0], a.st));
-    spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U><<<(unsigned)grid, kBlock, 0, a.st>>>(
-        pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add, a.ldadd,
-        a.od);
+    bool launched = false;
+    if constexpr (LPR == 64 && !DROPOUT && U == kUnroll) {
+        if (p->hot_cols > 0 && p->hot_cols < p->n_cols) {
+            pv.hot_cols = (uint32_t)p->hot_cols;
+            spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U, true><<<(unsigned)grid, kBlock, 0, a.st>>>(
+                pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add,
+                a.ldadd, a.od);
+            launched = true;
+        }
+    }
+    if (!launched)
+        spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U><<<(unsigned)grid, kBlock, 0, a.st>>>(
+            pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add,
+            a.ldadd, a.od);
     GCN_LAUNCH_CHECK();
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[1], a.st));
     if (lt.n_chunks > 0) {
@@ -931,6 +972,7 @@ int gcn_spmm_plan_create_split(int64_t n_rows, int64_t n_cols, int64_t nnz, cons
         p->table[t].chunk_long = nullptr;
     }
     p->timing = 0;
+    p->hot_cols = 0;
     p->ev[0] = p->ev[1] = p->ev[2] = nullptr;
     int32_t* d_rows = nullptr;
     int64_t *d_starts = nullptr, *d_ends = nullptr;
@@ -1062,6 +1104,12 @@ int gcn_spmm_plan_last_timing(const gcn_spmm_plan* plan, float* ms2) {
     GCN_HIP_TRY(hipEventSynchronize(plan->ev[2]));
     GCN_HIP_TRY(hipEventElapsedTime(&ms2[0], plan->ev[0], plan->ev[1]));
     GCN_HIP_TRY(hipEventElapsedTime(&ms2[1], plan->ev[1], plan->ev[2]));
+    return GCN_OK;
+}
+
+int gcn_spmm_plan_set_hot_columns(gcn_spmm_plan* plan, int64_t hot_cols) {
+    if (!plan || hot_cols < 0) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    plan->hot_cols = hot_cols;
     return GCN_OK;
 }
 

@@ -64,6 +64,10 @@ class SpmmPlan(object):
         self.n_strips, self.n_long_rows, self.n_chunks, self.split_nnz = (int(v) for v in info)
         self._ws = {}
 
+    def set_hot_columns(self, hot_cols):
+        """Rows of B from column ``hot_cols`` on are loaded non-temporally by wide products (0: off)."""
+        _lib.call('gcn_spmm_plan_set_hot_columns', self.handle, int(hot_cols))
+
     def set_timing(self, enable=True):
         """Record HIP events around the kernels of every product on this plan."""
         _lib.call('gcn_spmm_plan_set_timing', self.handle, 1 if enable else 0)
@@ -249,6 +253,47 @@ def csr_transpose(a):
     return DeviceCSR(a.n_cols, a.n_rows, t_indptr, t_indices, t_vals, perm=perm)
 
 
+def degree_order(indptr):
+    """Vertex order by descending row length (ties by ascending id): ``(new_id, old_id)`` int32 device
+    tensors with ``new_id[v]`` the position of vertex v and ``old_id[i]`` the vertex at position i."""
+    _require_cuda(indptr)
+    n = indptr.numel() - 1
+    ws_bytes = ctypes.c_size_t()
+    _lib.call('gcn_degree_order_bound', n, ctypes.byref(ws_bytes))
+    ws = _workspace(ws_bytes.value, indptr.device)
+    new_id = torch.empty(n, dtype=torch.int32, device=indptr.device)
+    old_id = torch.empty(n, dtype=torch.int32, device=indptr.device)
+    _lib.call('gcn_degree_order', n, _p(indptr), _p(new_id), _p(old_id), _p(ws), ws.numel(), _stream())
+    return new_id, old_id
+
+
+def csr_relabel(n_rows, n_cols, indptr, indices, vals=None, new_row=None, new_col=None):
+    """(indptr, indices, vals) of the matrix with entry (r, c) moved to (new_row[r], new_col[c]);
+    ``vals`` float64 or None (structure only)."""
+    _require_cuda(indptr, indices, vals, new_row, new_col)
+    dev = indptr.device
+    nnz = indices.numel()
+    if vals is not None:
+        vals = vals.to(torch.float64).contiguous()
+    for lab in (new_row, new_col):
+        if lab is not None and (lab.dtype != torch.int32 or not lab.is_contiguous()):
+            raise ValueError('labels must be contiguous int32 tensors')
+    if (new_row is not None and new_row.numel() != n_rows) or (new_col is not None and new_col.numel() != n_cols):
+        raise ValueError('one label per row / column')
+    ws_bytes = ctypes.c_size_t()
+    _lib.call('gcn_csr_relabel_bound', n_rows, nnz, 0 if vals is None else 1, ctypes.byref(ws_bytes))
+    ws = _workspace(ws_bytes.value, dev)
+    indptr_out = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+    indices_out = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    vals_out = None if vals is None else torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+    nnz_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.call('gcn_csr_relabel', n_rows, n_cols, nnz, _p(indptr), _p(indices.contiguous()), _p(vals), _p(new_row),
+              _p(new_col), _p(indptr_out), _p(indices_out), _p(vals_out), _p(nnz_out), _p(ws), ws.numel(), _stream())
+    m = int(nnz_out.item())
+    del ws
+    return indptr_out, indices_out[:m], (None if vals is None else vals_out[:m])
+
+
 def triple_to_device_csr(triple, device='cuda'):
     """Device CSR of a fed ``(indices [nnz,2], values, dense_shape)`` triple, values cast to
     float32 as the float32 sparse placeholder does (train.py:145-146).  The order of the entries
@@ -278,10 +323,10 @@ def triple_to_device_csr(triple, device='cuda'):
 # --------------------------------------------------------------------------- #
 # synthetic inputs
 # --------------------------------------------------------------------------- #
-def rmat_csr(scale, edge_factor=16, seed=42, self_loops=False, device='cuda'):
+def rmat_csr(scale, edge_factor=16, seed=42, self_loops=False, device='cuda', scramble=True):
     """CSR structure (indptr int64, indices int32) of the symmetrised, deduplicated R-MAT graph;
-    with ``self_loops`` the structure of A + I."""
-    flags = _lib.GCN_ADD_SELF_LOOPS if self_loops else 0
+    with ``self_loops`` the structure of A + I.  ``scramble=False`` keeps the generator's own vertex ids."""
+    flags = (_lib.GCN_ADD_SELF_LOOPS if self_loops else 0) | (0 if scramble else _lib.GCN_RMAT_NATURAL_ORDER)
     cap, ws_bytes = ctypes.c_int64(), ctypes.c_size_t()
     _lib.call('gcn_rmat_csr_bound', scale, edge_factor, flags, ctypes.byref(cap), ctypes.byref(ws_bytes))
     n = 1 << scale

@@ -39,6 +39,7 @@ typedef enum {
 /* flags of gcn_coo_to_csr */
 #define GCN_ADD_SELF_LOOPS 1  /* adj + sp.eye(n): ADD 1.0 on the diagonal            (gcn/utils.py:321) */
 #define GCN_BINARY 2          /* duplicates collapse to one entry of value 1 (simple graph, no values out) */
+#define GCN_RMAT_NATURAL_ORDER 8 /* gcn_rmat_csr: keep the generator's own vertex ids (hubs at the ids with few one-bits) */
 /* flags of the SpMM / GEMM entry points */
 #define GCN_RELU 1            /* act = relu fused into the epilogue                  (gcn/layers.py:214, models.py:17) */
 #define GCN_SPLIT_WIDE 4      /* spmm: cut long rows every 1024 entries whatever the width, so that a product
@@ -103,6 +104,27 @@ int gcn_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
                       const void* vals, int val_bytes, int64_t* t_indptr, int32_t* t_indices, void* t_vals,
                       int64_t* perm_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Vertex order by descending degree (row length), ties by ascending id: new_id_out[v] = position of
+ * vertex v in that order, old_id_out[i] = the vertex at position i (either may be NULL).  An integer
+ * preprocessing step in front of preprocess_adj (gcn/utils.py:318-323); the reference keeps the
+ * dataset's order.  After it the hub rows of the dense operand are its first rows -- one contiguous,
+ * cache-resident block -- and rows of similar length sit next to each other. */
+int gcn_degree_order_bound(int64_t n_rows, size_t* workspace_bytes);
+int gcn_degree_order(int64_t n_rows, const int64_t* indptr, int32_t* new_id_out, int32_t* old_id_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* CSR of P_r . A . P_c^T: entry (r, c) moves to (new_row[r], new_col[c]); columns ascend inside every
+ * output row.  new_row / new_col NULL = identity; labels outside the shape are GCN_ERR_INDEX_RANGE.
+ * vals (float64, with vals_out) may be NULL for a structure-only matrix.  With new_row == new_col of a
+ * symmetric adjacency this is the relabelled graph of gcn_degree_order; products on it equal the
+ * original ones with the rows of B and C permuted the same way (gcn_gather_rows_f32), up to the order
+ * of the additions inside a row.  [sync] */
+int gcn_csr_relabel_bound(int64_t n_rows, int64_t nnz, int valued, size_t* workspace_bytes);
+int gcn_csr_relabel(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, const int32_t* indices,
+                    const double* vals, const int32_t* new_row, const int32_t* new_col, int64_t* indptr_out,
+                    int32_t* indices_out, double* vals_out, int64_t* nnz_out, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
 /* Range check of CSR column indices: GCN_ERR_INDEX_RANGE if any is outside
  * [0, n_cols) -- the check TensorFlow's kernel makes per nonzero.  [sync] */
 int gcn_check_indices(int64_t nnz, const int32_t* indices, int64_t n_cols, void* stream);
@@ -115,7 +137,7 @@ int gcn_rmat_csr_bound(int scale, int edge_factor, int flags, int64_t* nnz_capac
 
 /* R-MAT (a,b,c,d)=(0.57,0.19,0.19,0.05), edge_factor*2^scale generated pairs,
  * vertex ids scrambled by a fixed bijection (so that contiguous row blocks carry
- * equal work), self-loops dropped, symmetrised, deduplicated -> CSR structure of
+ * equal work; GCN_RMAT_NATURAL_ORDER leaves them as generated), self-loops dropped, symmetrised, deduplicated -> CSR structure of
  * a simple undirected graph (the kind nx.from_dict_of_lists builds at
  * gcn/utils.py:123).  flags: GCN_ADD_SELF_LOOPS also inserts every (i, i), giving
  * the structure of A + I (all values 1).  Integer-only, counter-based: identical
@@ -146,6 +168,12 @@ int gcn_spmm_plan_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
 int gcn_spmm_plan_create_split(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr, int64_t split_entries,
                                gcn_spmm_plan** plan_out, void* stream);
 int gcn_spmm_plan_destroy(gcn_spmm_plan* plan);
+/* Cache hint for products with this plan (wide dense operands, one wave per row): rows of B whose
+ * column index is >= hot_cols are loaded with the non-temporal hint, the first hot_cols rows with the
+ * default policy.  Meant for a matrix relabelled by gcn_degree_order, whose hub columns come first; 0
+ * (default) turns the hint off.  Results do not change.  No counterpart in the reference (its kernel,
+ * gcn/layers.py:31, runs on a CPU). */
+int gcn_spmm_plan_set_hot_columns(gcn_spmm_plan* plan, int64_t hot_cols);
 /* host-side facts about a plan: what[0]=n_strips, [1]=rows longer than the split threshold, [2]=their
  * chunks, [3]=the split threshold (the smallest one: rows up to it are summed serially for every width) */
 int gcn_spmm_plan_info(const gcn_spmm_plan* plan, int64_t* what4);

@@ -107,14 +107,16 @@ def scramble_id(v, bits, key):
     return x
 
 
-def rmat_csr(scale, edge_factor=16, seed=42, self_loops=False):
-    """Simple undirected graph: scramble ids, drop self-loops, symmetrise, sort, dedupe -> CSR
-    structure; ``self_loops`` adds every (i, i) (the structure of A + I)."""
+def rmat_csr(scale, edge_factor=16, seed=42, self_loops=False, scramble=True):
+    """Simple undirected graph: scramble ids (unless ``scramble=False``), drop self-loops, symmetrise,
+    sort, dedupe -> CSR structure; ``self_loops`` adds every (i, i) (the structure of A + I)."""
     u, v = rmat_pairs(scale, edge_factor, seed)
     keep = u != v
-    label_key = stream_key(seed, 1)
-    u = scramble_id(u[keep], scale, label_key).astype(np.int64)
-    v = scramble_id(v[keep], scale, label_key).astype(np.int64)
+    u, v = u[keep], v[keep]
+    if scramble:
+        label_key = stream_key(seed, 1)
+        u = scramble_id(u, scale, label_key).astype(np.int64)
+        v = scramble_id(v, scale, label_key).astype(np.int64)
     keys = np.concatenate([(u << 32) | v, (v << 32) | u])
     n = 1 << scale
     if self_loops:
@@ -126,6 +128,27 @@ def rmat_csr(scale, edge_factor=16, seed=42, self_loops=False):
     indptr = np.zeros(n + 1, dtype=np.int64)
     np.add.at(indptr, rows + 1, 1)
     return np.cumsum(indptr), cols
+
+
+def degree_order(indptr):
+    """Vertices by descending row length, ties by ascending id: (new_id, old_id) int32."""
+    deg = np.diff(np.asarray(indptr, dtype=np.int64))
+    old_id = np.lexsort((np.arange(deg.size), -deg)).astype(np.int32)
+    new_id = np.empty_like(old_id)
+    new_id[old_id] = np.arange(deg.size, dtype=np.int32)
+    return new_id, old_id
+
+
+def csr_relabel(n_rows, indptr, indices, vals, new_row, new_col):
+    """CSR of the matrix with entry (r, c) moved to (new_row[r], new_col[c]), columns ascending."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(indptr))
+    r = np.asarray(new_row, dtype=np.int64)[rows]
+    c = np.asarray(new_col, dtype=np.int64)[np.asarray(indices, dtype=np.int64)]
+    order = np.lexsort((c, r))
+    out_ip = np.zeros(n_rows + 1, dtype=np.int64)
+    np.add.at(out_ip, r + 1, 1)
+    return np.cumsum(out_ip), c[order].astype(np.int32), (None if vals is None else np.asarray(vals)[order])
 
 
 # --------------------------------------------------------------------------- #

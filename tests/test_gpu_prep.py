@@ -244,3 +244,70 @@ def test_out_of_range_coo_indices_are_rejected_before_any_write():
     # the valid part still converts
     ip, ix, _ = sparse.coo_to_csr(n, n, good_r, good_c, binary=True)
     assert ip.cpu().tolist() == [0, 1, 2, 3, 3, 3, 4] and ix.cpu().tolist() == [1, 0, 3, 5]
+
+
+def test_degree_order_and_relabel_against_the_oracle(graph_fx, oracle):
+    """Degree-descending vertex order and the relabelled CSR (integer work: bit-exact), then the product on
+    the relabelled A_hat against the original one with B and C permuted the same way."""
+    import torch
+    from gcn_amd import sparse
+    name, fx = graph_fx
+    n = int(fx['n'])
+    ip, ix, data = fx['ai_indptr'].astype(np.int64), fx['ai_indices'], fx['ai_data']
+    d_ip, d_ix = _t(ip, torch.int64), _t(ix)
+    new_id, old_id = sparse.degree_order(d_ip)
+    ref_new, ref_old = oracle.degree_order(ip)
+    assert np.array_equal(new_id.cpu().numpy(), ref_new) and np.array_equal(old_id.cpu().numpy(), ref_old)
+    r_ip, r_ix, r_v = sparse.csr_relabel(n, n, d_ip, d_ix, _t(data), new_id, new_id)
+    o_ip, o_ix, o_v = oracle.csr_relabel(n, ip, ix, data, ref_new, ref_new)
+    assert np.array_equal(r_ip.cpu().numpy(), o_ip) and np.array_equal(r_ix.cpu().numpy(), o_ix)
+    assert np.array_equal(r_v.cpu().numpy(), o_v)
+    lens = np.diff(o_ip)
+    assert np.all(lens[:-1] >= lens[1:])                                  # hub rows first
+    # structure only, and a rectangular relabel of the columns alone
+    s_ip, s_ix, s_v = sparse.csr_relabel(n, n, d_ip, d_ix, None, None, new_id)
+    c_ip, c_ix, _ = oracle.csr_relabel(n, ip, ix, None, np.arange(n), ref_new)
+    assert s_v is None and np.array_equal(s_ip.cpu().numpy(), c_ip) and np.array_equal(s_ix.cpu().numpy(), c_ix)
+    # the product: A_hat' . B' with B' = B[old_id] equals (A_hat . B)[old_id] up to the order of additions
+    hat = fx['hat_values'].astype(np.float32)
+    a = sparse.DeviceCSR(n, n, d_ip, d_ix, _t(hat))
+    h_ip, h_ix, h_v = sparse.csr_relabel(n, n, d_ip, d_ix, _t(fx['hat_values']), new_id, new_id)
+    a2 = sparse.DeviceCSR(n, n, h_ip, h_ix.contiguous(), h_v.to(torch.float32))
+    b = sparse.synthetic_dense(n, 64, seed=8)
+    c = sparse.spmm(a, b)
+    old64 = old_id.to(torch.int64)
+    b2 = torch.empty_like(b)
+    sparse.gather_rows(b, old64, b2)
+    c2 = sparse.spmm(a2, b2)
+    back = torch.empty_like(c)
+    sparse.gather_rows(c2, new_id.to(torch.int64), back)                # permuted back to the original ids
+    assert float((back - c).abs().max()) <= 1e-5 * float(c.abs().max())
+    # a label outside the shape is refused
+    bad = new_id.clone()
+    bad[3] = n
+    with pytest.raises(ValueError, match='outside'):
+        sparse.csr_relabel(n, n, d_ip, d_ix, None, bad, new_id)
+
+
+def test_rmat_natural_order_and_hot_column_hint(oracle):
+    """The generator without the id scramble equals the oracle's; the non-temporal hint on cold columns
+    (gcn_spmm_plan_set_hot_columns) changes no bit of a wide product."""
+    import torch
+    from gcn_amd import sparse
+    scale = 14
+    ip, ix = sparse.rmat_csr(scale, 16, seed=42, self_loops=True, scramble=False)
+    o_ip, o_ix = oracle.rmat_csr(scale, 16, seed=42, self_loops=True, scramble=False)
+    assert np.array_equal(ip.cpu().numpy(), o_ip) and np.array_equal(ix.cpu().numpy(), o_ix)
+    n = 1 << scale
+    lens = np.diff(o_ip)
+    assert lens[0] == lens.max()                                        # vertex 0 is the largest hub
+    d = sparse.degree_scale(sparse.row_sums(ip, None), 'sym')
+    v = sparse.normalize_values(ip, ix, None, d, 'sym', want64=False)[1]
+    a = sparse.DeviceCSR(n, n, ip, ix, v)
+    for f in (256, 512):
+        b = sparse.synthetic_dense(n, f, seed=2)
+        plain = sparse.spmm(a, b)
+        for hot in (1, 64, n // 2):
+            a.plan.set_hot_columns(hot)
+            assert torch.equal(sparse.spmm(a, b), plain)
+        a.plan.set_hot_columns(0)
