@@ -76,18 +76,48 @@ def build_graph(scale, edge_factor):
     return indptr, indices, vals
 
 
+def kernel_source_hash():
+    """sha256 of the product kernels' source: a counter record is only quoted for the source it was taken on."""
+    import hashlib
+    with open(os.path.join(ROOT, 'gcn_amd', 'csrc', 'spmm.hip'), 'rb') as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
 def measured_traffic(kernel, scale, edge_factor, f, world):
-    """HBM-side bytes per launch of the row kernel from the rocprofv3 PMC passes kept under profiles/
-    (FETCH_SIZE and WRITE_SIZE cannot share a pass, so they come from separate runs of this same
-    command; corrected as (2 * FETCH_SIZE + WRITE_SIZE) * 1024).  None when no record matches."""
+    """Bytes per launch that the row kernel moves BEHIND THE L2 (read requests of the L2 to the fabric x
+    128 bytes + WRITE_SIZE), from the rocprofv3 counter passes recorded in profiles/traffic.json.  This
+    is L2-miss traffic: what the Infinity Cache serves is included, so it bounds the HBM bytes from
+    above.  The record names the profile it comes from and the hash of the kernel source it was taken
+    on; with another source, or no matching record, the answer is None."""
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
     if world != 1 or not os.path.exists(path):
         return None
     with open(path) as fh:
         for rec in json.load(fh):
             if (rec['kernel'], rec['scale'], rec['edge_factor'], rec['features']) == (kernel, scale, edge_factor, f):
-                return rec['hbm_bytes_per_launch']
+                if rec.get('spmm_hip_sha256') != kernel_source_hash():
+                    return None
+                return rec
     return None
+
+
+def host_description():
+    """Core counts and CPU model of the host the CPU baseline runs on."""
+    model = None
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = None
+    return {'os_cpu_count': os.cpu_count(), 'cpus_this_process_may_use': usable, 'cpu_model': model,
+            'OMP_NUM_THREADS': os.environ.get('OMP_NUM_THREADS')}
 
 
 def planetoid_epoch_ms(name, epochs=60, hip_graph=False):
@@ -114,8 +144,14 @@ def planetoid_epoch_ms(name, epochs=60, hip_graph=False):
 
 
 def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, classes=16, chunks=4):
-    """One training step (forward + backward + Adam, train.py:203-205) of a 2-layer GCN
-    features -> hidden -> classes on the bench graph, rows sharded over the ranks."""
+    """One training step (forward + backward + Adam: the region train.py:203-205 times) of a 2-layer GCN
+    features -> hidden -> classes on the bench graph, rows sharded over the ranks, in two forms:
+
+    ``reference_order_ms``: the reference's own order of operations -- every layer as A_hat . (X' . W)
+    (gcn/layers.py:198-202) over all rows, with the backward products that order implies.  This is
+    the "GCN epoch ms" of the metric.
+    ``ms``: the same step, same loss and weights to rounding, restructured: first layer as (A_hat . X') . W0
+    and hidden rows formed only where a labelled node reads them."""
     import torch
     from gcn_amd.dist_train import ShardedGCN
     r0, r1 = shard.row_begin, shard.row_end
@@ -123,29 +159,40 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, cl
     labels = torch.nn.functional.one_hot((rows * 2654435761 >> 7) % classes, classes).to(torch.int32)
     mask = (rows % 64 == 0).to(torch.int32)
     del rows
-    model = ShardedGCN(shard, x_local.shape[1], [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
-                       seed=123, chunks=chunks)
-    for _ in range(warmup):
-        model.train_step(x_local, labels, mask)
-    if group_world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = model.train_step(x_local, labels, mask)
-    if group_world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    if group_world > 1:
-        t = torch.tensor([ms], dtype=torch.float64, device=x_local.device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        ms = float(t.item())
-    return {'ms': ms, 'loss': float(loss), 'layers': [int(x_local.shape[1]), hidden, classes], 'steps': steps,
-            'what': 'forward + backward + Adam, dropout 0.5, one labelled node in 64, rows/%d; first layer as %s%s' % (
-                group_world, "(A.X').W0: no backward product" if model.aggregate_first else "A.(X'.W0)",
-                '; hidden rows formed only where a labelled node reads them'
-                if (model.receptive_field and model.aggregate_first) else '')}
+
+    def timed(**form):
+        model = ShardedGCN(shard, x_local.shape[1], [hidden], classes, learning_rate=0.02, weight_decay=5e-4,
+                           dropout=0.5, seed=123, chunks=chunks, **form)
+        for _ in range(warmup):
+            model.train_step(x_local, labels, mask)
+        if group_world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = model.train_step(x_local, labels, mask)
+        if group_world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        if group_world > 1:
+            t = torch.tensor([ms], dtype=torch.float64, device=x_local.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            ms = float(t.item())
+        described = (model.aggregate_first, model.receptive_field and model.aggregate_first)
+        loss = float(loss)
+        del model
+        torch.cuda.empty_cache()
+        return ms, loss, described
+
+    ref_ms, ref_loss, _ = timed(aggregate_first=False, receptive_field=False)
+    ms, loss, (aggregated, pruned) = timed()
+    return {'reference_order_ms': ref_ms, 'reference_order_loss': ref_loss, 'ms': ms, 'loss': loss,
+            'layers': [int(x_local.shape[1]), hidden, classes], 'steps': steps,
+            'what': 'forward + backward + Adam, dropout 0.5, one labelled node in 64, rows/%d.  reference_order_ms: '
+                    "every layer as A.(X'.W) over all rows (gcn/layers.py:198-202).  ms: first layer as %s%s" % (
+                        group_world, "(A.X').W0 (no backward product)" if aggregated else "A.(X'.W0)",
+                        ', hidden rows formed only where a labelled node reads them' if pruned else '')}
 
 
 def cpu_baseline(a, b_dev, c_dev, row_stride):
@@ -171,7 +218,8 @@ def cpu_baseline(a, b_dev, c_dev, row_stride):
     t0 = time.perf_counter()
     oracle.spmm_csr(ip, ix, vv, b, threads=1, out=out)
     t_serial = time.perf_counter() - t0
-    threads = min(oracle._load_clib().oracle_num_threads(), 16)
+    # every thread OpenMP gives this process (the box caps OMP_NUM_THREADS at its CPU share)
+    threads = oracle._load_clib().oracle_num_threads()
     t0 = time.perf_counter()
     out_mt = oracle.spmm_csr(ip, ix, vv, b, threads=threads)
     t_mt = time.perf_counter() - t0
@@ -189,6 +237,9 @@ def cpu_baseline(a, b_dev, c_dev, row_stride):
             'sample': sample, 'seconds': t_serial}
     allcores = {'value': full * frac / t_mt / 1e9, 'unit': 'GB/s', 'cores': threads, 'kind': 'port',
                 'sample': sample, 'seconds': t_mt}
+    host = host_description()
+    base['host'] = host
+    allcores['host'] = host
     check = {'rows_checked': int(rows.numel()), 'short_rows_bit_exact': exact, 'max_rel_err': max_err}
     return base, allcores, check
 
@@ -218,11 +269,11 @@ def main():
 
     n = 1 << args.scale
     f = args.features
-    indptr, indices, vals = build_graph(args.scale, args.edge_factor)
-    nnz = int(indices.numel())
-    b_full = sparse.synthetic_dense(n, f, seed=7)
 
     if world == 1:
+        indptr, indices, vals = build_graph(args.scale, args.edge_factor)
+        nnz = int(indices.numel())
+        b_full = sparse.synthetic_dense(n, f, seed=7)
         a = sparse.DeviceCSR(n, n, indptr, indices, vals)
         c = torch.empty((n, f), dtype=torch.float32, device=dev)
         a.plan.set_timing(True)
@@ -232,10 +283,12 @@ def main():
         def step():
             sparse.spmm(a, b_full, out=c)
     else:
-        shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, rank, world)
-        del indptr, indices, vals
-        b_local = b_full[shard.row_begin:shard.row_end].clone()
-        del b_full
+        # every rank generates its own row block of A_hat and of B and nothing else
+        shard = gdist.rmat_shard(args.scale, args.edge_factor, rank, world, seed=42)
+        b_local = sparse.synthetic_dense(shard.row_end - shard.row_begin, f, seed=7, first_row=shard.row_begin)
+        t = torch.tensor([shard.local.nnz], dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(t)
+        nnz = int(t.item())
         torch.cuda.empty_cache()
         op = gdist.HaloSpmm(shard, f, chunks=args.chunks) if not args.allgather else gdist.AllGatherSpmm(shard, f)
         a = op.compact if not args.allgather else shard.local
@@ -295,7 +348,7 @@ def main():
             'gather_gbps': total_gather / (ms_per_step * 1e-3) / 1e9,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS,
-                         'traffic': measured_traffic('spmm_rows_kernel', args.scale, args.edge_factor, f, world),
+                         'traffic': None,
                          'kernel': 'spmm_rows_kernel', 'kernel_ms': row_ms, 'reduce_kernel_ms': red_ms,
                          'algorithmic_bytes': local_min, 'launch_features': f_launch},
             'pipeline_candidates_ms': ([{'ranges': r, 'ms': t} for r, t in tuned] if (world > 1 and tuned) else None),
@@ -312,9 +365,12 @@ def main():
                     line['gcn_epoch'].append(planetoid_epoch_ms(name, hip_graph=recorded))
                 except Exception as exc:
                     line['gcn_epoch'].append({'dataset': name, 'error': '%s: %s' % (type(exc).__name__, exc)})
-        t = line['roofline']['traffic']
-        if t:
-            line['hbm_measured_gbps'] = t / (row_ms * 1e-3) / 1e9
+        rec = measured_traffic('spmm_rows_kernel', args.scale, args.edge_factor, f, world)
+        if rec:
+            # bytes behind the L2 per launch (Infinity-Cache hits included: an upper bound of the HBM bytes)
+            line['roofline']['traffic'] = rec['l2_miss_bytes_per_launch']
+            line['roofline']['traffic_source'] = rec['source']
+            line['l2_miss_traffic_gbps'] = rec['l2_miss_bytes_per_launch'] / (row_ms * 1e-3) / 1e9
     ranges_used = list(op.ranges) if (world > 1 and not args.allgather) else None
     # GCN epoch on the same graph, every rank takes part
     epoch = None
@@ -328,7 +384,7 @@ def main():
                 if rank == 0:
                     line['gcn_epoch_rmat'] = {'error': 'no result within %d s' % EPOCH_LIMIT_S}
                     print(json.dumps(line), flush=True)
-                os._exit(0)
+                os._exit(3)                 # the product's line is out; the hang itself is a failure
         watchdog = threading.Timer(EPOCH_LIMIT_S, give_up)
         watchdog.daemon = True
         watchdog.start()
@@ -349,13 +405,17 @@ def main():
         watchdog.cancel()
     if not printed.acquire(False):
         time.sleep(60)                      # the timer thread is printing and ends the process
+    failed = epoch is not None and 'error' in epoch
     if rank == 0:
         if epoch is not None:
             line['gcn_epoch_rmat'] = epoch
-        print(json.dumps(line))
+        failed = failed or any('error' in leg for leg in line.get('gcn_epoch', []))
+        print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if failed:
+        sys.exit(1)                         # a leg raised: the line above says which; do not report success
 
 
 if __name__ == '__main__':

@@ -51,7 +51,11 @@ SIGNATURES = {
     'gcn_check_indices': [_i64, _vp, _i64, _vp],
     'gcn_rmat_csr_bound': [_int, _int, _int, _pi64, _psz],
     'gcn_rmat_csr': [_int, _int, _u64, _int, _vp, _vp, _vp, _vp, _sz, _vp],
+    'gcn_rmat_rows_count': [_int, _int, _u64, _int, _i64, _i64, _pi64, _vp],
+    'gcn_rmat_csr_rows_bound': [_i64, _psz],
+    'gcn_rmat_csr_rows': [_int, _int, _u64, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp],
     'gcn_fill_synthetic_f32': [_i64, _u64, _vp, _vp],
+    'gcn_fill_synthetic_range_f32': [_i64, _i64, _u64, _vp, _vp],
     'gcn_spmm_plan_create': [_i64, _i64, _i64, _vp, ctypes.POINTER(_vp), _vp],
     'gcn_spmm_plan_create_split': [_i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_vp), _vp],
     'gcn_spmm_plan_destroy': [_vp],

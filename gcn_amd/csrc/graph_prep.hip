@@ -394,11 +394,57 @@ __global__ void rmat_keys_kernel(int scale, int64_t n_pairs, int64_t n_loops, ui
     }
 }
 
-__global__ void fill_synthetic_kernel(int64_t count, uint64_t key, float* __restrict__ out) {
+__global__ void fill_synthetic_kernel(int64_t count, uint64_t key, uint64_t first, float* __restrict__ out) {
     GCN_GRID_STRIDE(i, count) {
-        const int32_t hi = (int32_t)(uint32_t)(sm64(key ^ (uint64_t)i) >> 32);
+        const int32_t hi = (int32_t)(uint32_t)(sm64(key ^ (first + (uint64_t)i)) >> 32);
         out[i] = (float)(hi >> 8) * 1.1920928955078125e-07f;  // 2^-23
     }
+}
+
+// The generated pair e of the R-MAT stream, ids scrambled or not: the arithmetic of rmat_keys_kernel.
+__device__ __forceinline__ void rmat_pair(int scale, uint64_t key, uint64_t label_key, int scramble, uint32_t ta,
+                                          uint32_t tb, uint32_t tc, int64_t e, uint64_t* u_out, uint64_t* v_out,
+                                          bool* loop_out) {
+    uint64_t u = 0, v = 0;
+    for (int level = 0; level < scale; ++level) {
+        const uint32_t r = (uint32_t)(sm64(key ^ ((uint64_t)e * (uint64_t)scale + (uint64_t)level)) >> 32);
+        const uint32_t q = (r >= ta) + (r >= tb) + (r >= tc);
+        u = (u << 1) | (q >> 1);
+        v = (v << 1) | (q & 1);
+    }
+    *loop_out = (u == v);
+    if (scramble) {
+        u = scramble_id(u, scale, label_key);
+        v = scramble_id(v, scale, label_key);
+    }
+    *u_out = u;
+    *v_out = v;
+}
+
+// Keys of the rows [row_begin, row_end) only.  keys == nullptr: count them.  Otherwise every key takes the
+// next free slot (the order of the slots does not matter: the keys are sorted afterwards).
+__global__ void rmat_rows_keys_kernel(int scale, int64_t n_pairs, uint64_t key, uint64_t label_key, int scramble,
+                                      uint32_t ta, uint32_t tb, uint32_t tc, uint64_t row_begin, uint64_t row_end,
+                                      unsigned long long* __restrict__ counter, int64_t capacity,
+                                      uint64_t* __restrict__ keys) {
+    GCN_GRID_STRIDE(e, n_pairs) {
+        uint64_t u, v;
+        bool loop;
+        rmat_pair(scale, key, label_key, scramble, ta, tb, tc, e, &u, &v, &loop);
+        if (loop) continue;
+        const bool mine_u = u >= row_begin && u < row_end, mine_v = v >= row_begin && v < row_end;
+        const int n_mine = (mine_u ? 1 : 0) + (mine_v ? 1 : 0);
+        if (n_mine == 0) continue;
+        const unsigned long long slot = atomicAdd(counter, (unsigned long long)n_mine);
+        if (!keys) continue;
+        int64_t at = (int64_t)slot;
+        if (mine_u && at < capacity) keys[at++] = ((u - row_begin) << 32) | v;
+        if (mine_v && at < capacity) keys[at] = ((v - row_begin) << 32) | u;
+    }
+}
+
+__global__ void diagonal_keys_kernel(int64_t n_local, uint64_t row_begin, uint64_t* __restrict__ keys) {
+    GCN_GRID_STRIDE(i, n_local) keys[i] = ((uint64_t)i << 32) | (row_begin + (uint64_t)i);
 }
 
 // bit 0: a row index outside [0, n_rows); bit 1: a column index outside [0, n_cols)
@@ -717,11 +763,108 @@ int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int flags, int64_t* 
 }
 
 int gcn_fill_synthetic_f32(int64_t count, uint64_t seed, float* out, void* stream) {
-    if (count < 0 || (count > 0 && !out)) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    return gcn_fill_synthetic_range_f32(0, count, seed, out, stream);
+}
+
+int gcn_fill_synthetic_range_f32(int64_t first, int64_t count, uint64_t seed, float* out, void* stream) {
+    if (first < 0 || count < 0 || (count > 0 && !out)) return fail(GCN_ERR_BAD_ARG, "bad argument");
     if (count == 0) return GCN_OK;
-    fill_synthetic_kernel<<<grid_for(count), kBlock, 0, (hipStream_t)stream>>>(count, stream_key(seed, 0), out);
+    fill_synthetic_kernel<<<grid_for(count), kBlock, 0, (hipStream_t)stream>>>(count, stream_key(seed, 0),
+                                                                                (uint64_t)first, out);
     GCN_LAUNCH_CHECK();
     return GCN_OK;
+}
+
+static int rmat_rows_args(int scale, int edge_factor, int flags, int64_t row_begin, int64_t row_end) {
+    if (scale < 1 || scale > 30 || edge_factor < 1) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (flags & ~(GCN_ADD_SELF_LOOPS | GCN_RMAT_NATURAL_ORDER))
+        return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    if (row_begin < 0 || row_end < row_begin || row_end > ((int64_t)1 << scale))
+        return fail(GCN_ERR_BAD_ARG, "bad row range [%lld, %lld)", (long long)row_begin, (long long)row_end);
+    return GCN_OK;
+}
+
+static void rmat_thresholds(uint32_t* ta, uint32_t* tb, uint32_t* tc) {
+    *ta = (uint32_t)(0.57 * 4294967296.0);
+    *tb = (uint32_t)((0.57 + 0.19) * 4294967296.0);
+    *tc = (uint32_t)((0.57 + 0.19 + 0.19) * 4294967296.0);
+}
+
+int gcn_rmat_rows_count(int scale, int edge_factor, uint64_t seed, int flags, int64_t row_begin, int64_t row_end,
+                        int64_t* n_keys_host, void* stream) {
+    int rc = rmat_rows_args(scale, edge_factor, flags, row_begin, row_end);
+    if (rc != GCN_OK) return rc;
+    if (!n_keys_host) return fail(GCN_ERR_BAD_ARG, "n_keys_host is null");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_pairs = (int64_t)edge_factor << scale;
+    uint32_t ta, tb, tc;
+    rmat_thresholds(&ta, &tb, &tc);
+    unsigned long long* counter = nullptr;
+    GCN_HIP_TRY(hipMalloc(&counter, sizeof(unsigned long long)));
+    unsigned long long host = 0;
+    hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) {
+        rmat_rows_keys_kernel<<<grid_for(n_pairs), kBlock, 0, st>>>(
+            scale, n_pairs, stream_key(seed, 0), stream_key(seed, 1), (flags & GCN_RMAT_NATURAL_ORDER) ? 0 : 1, ta, tb,
+            tc, (uint64_t)row_begin, (uint64_t)row_end, counter, 0, nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, counter, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(counter);
+    if (e != hipSuccess) return fail(GCN_ERR_HIP, "counting the keys failed: %s", hipGetErrorString(e));
+    *n_keys_host = (int64_t)host + ((flags & GCN_ADD_SELF_LOOPS) ? (row_end - row_begin) : 0);
+    return GCN_OK;
+}
+
+int gcn_rmat_csr_rows_bound(int64_t n_keys, size_t* workspace_bytes) {
+    if (n_keys < 0 || !workspace_bytes) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    *workspace_bytes = sort_scratch_bytes(n_keys, false) + 256;
+    return GCN_OK;
+}
+
+int gcn_rmat_csr_rows(int scale, int edge_factor, uint64_t seed, int flags, int64_t row_begin, int64_t row_end,
+                      int64_t n_keys, int64_t* indptr_out, int32_t* indices_out, int64_t* nnz_out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    int rc = rmat_rows_args(scale, edge_factor, flags, row_begin, row_end);
+    if (rc != GCN_OK) return rc;
+    if (n_keys < 0 || !indptr_out || !nnz_out || (n_keys > 0 && !indices_out))
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_local = row_end - row_begin;
+    const int64_t n_loops = (flags & GCN_ADD_SELF_LOOPS) ? n_local : 0;
+    if (n_keys < n_loops) return fail(GCN_ERR_BAD_ARG, "n_keys is smaller than the number of diagonal entries");
+    size_t need = 0;
+    gcn_rmat_csr_rows_bound(n_keys, &need);
+    if (!workspace || workspace_bytes < need)
+        return fail(GCN_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    if (((uintptr_t)workspace & 255) != 0) return fail(GCN_ERR_BAD_ARG, "workspace must be 256-byte aligned");
+    unsigned long long* counter = (unsigned long long*)workspace;       // the first 256 bytes
+    SortScratch s;
+    rc = carve_scratch((char*)workspace + 256, workspace_bytes - 256, n_keys, false, &s);
+    if (rc != GCN_OK) return rc;
+    GCN_HIP_TRY(hipMemsetAsync(counter, 0, 256, st));
+    if (n_loops > 0) {
+        diagonal_keys_kernel<<<grid_for(n_loops), kBlock, 0, st>>>(n_loops, (uint64_t)row_begin, s.keys_a);
+        GCN_LAUNCH_CHECK();
+    }
+    const int64_t n_pairs = (int64_t)edge_factor << scale;
+    const int64_t capacity = n_keys - n_loops;
+    uint32_t ta, tb, tc;
+    rmat_thresholds(&ta, &tb, &tc);
+    rmat_rows_keys_kernel<<<grid_for(n_pairs), kBlock, 0, st>>>(
+        scale, n_pairs, stream_key(seed, 0), stream_key(seed, 1), (flags & GCN_RMAT_NATURAL_ORDER) ? 0 : 1, ta, tb, tc,
+        (uint64_t)row_begin, (uint64_t)row_end, counter, capacity, s.keys_a + n_loops);
+    GCN_LAUNCH_CHECK();
+    // n_keys must be the count gcn_rmat_rows_count returned for these arguments: every slot is then filled
+    unsigned long long emitted = 0;
+    GCN_HIP_TRY(hipMemcpyAsync(&emitted, counter, sizeof(emitted), hipMemcpyDeviceToHost, st));
+    GCN_HIP_TRY(hipStreamSynchronize(st));
+    if ((int64_t)emitted != capacity)
+        return fail(GCN_ERR_BAD_ARG, "n_keys=%lld does not match the %lld keys of this row range", (long long)n_keys,
+                    (long long)emitted + (long long)n_loops);
+    const unsigned key_bits = 32 + bits_for((uint64_t)(n_local > 0 ? n_local - 1 : 0));
+    return sorted_merge_to_csr(&s, n_keys, false, 2, key_bits, n_local, indptr_out, indices_out, nullptr, nnz_out, st);
 }
 
 }  // extern "C"

@@ -76,6 +76,35 @@ class RowShardedCSR(object):
         return cls(n_rows, n_cols, r0, r1, local, rank, world)
 
 
+def rmat_shard(scale, edge_factor, rank, world, seed=42, group=None, device='cuda'):
+    """This rank's rows of A_hat = D^-1/2 (A + I) D^-1/2 of the R-MAT graph, generated without ever
+    holding the other rows: the counter-based generator emits only the keys of the rank's row block
+    (``sparse.rmat_csr_rows``), the ranks all-gather their degree vectors (8 bytes per vertex) and every
+    rank scales its own entries.  Equal bit for bit to ``RowShardedCSR.from_full`` of the whole graph."""
+    n = 1 << scale
+    r0, r1 = row_block(n, rank, world)
+    indptr, indices = sparse.rmat_csr_rows(scale, r0, r1, edge_factor, seed, self_loops=True, device=device)
+    deg_local = (indptr[1:] - indptr[:-1]).to(torch.float64)          # row sums of A + I: every value is 1
+    if world > 1:
+        deg = torch.empty(n, dtype=torch.float64, device=deg_local.device)
+        all_gather_rows(deg, deg_local.contiguous(), group=group)
+    else:
+        deg = deg_local
+    d = sparse.degree_scale(deg, 'sym')
+    del deg, deg_local
+    # the scaling kernel looks d up by row number: give it the row pointers of the whole matrix, in
+    # which the rows of the other ranks are empty
+    nnz = int(indices.numel())
+    whole = torch.empty(n + 1, dtype=torch.int64, device=indptr.device)
+    whole[:r0] = 0
+    whole[r0:r1 + 1] = indptr
+    whole[r1 + 1:] = nnz
+    vals = sparse.normalize_values(whole, indices, None, d, 'sym', want64=False)[1]
+    del whole, d
+    local = sparse.DeviceCSR(r1 - r0, n, indptr, indices, vals)
+    return RowShardedCSR(n, n, r0, r1, local, rank, world)
+
+
 def shard_with_columns(shard, col_keep):
     """The shard restricted to the columns flagged in ``col_keep`` (bool, one flag per global column),
     entry order inside every row unchanged.  When the unflagged rows of the dense operand are zero --

@@ -341,9 +341,31 @@ def rmat_csr(scale, edge_factor=16, seed=42, self_loops=False, device='cuda', sc
     return indptr, indices[:nnz].clone()
 
 
-def synthetic_dense(n, f, seed=7, device='cuda'):
+def rmat_csr_rows(scale, row_begin, row_end, edge_factor=16, seed=42, self_loops=False, device='cuda',
+                  scramble=True):
+    """The rows [row_begin, row_end) of ``rmat_csr``'s graph (indptr from 0, global column indices)
+    without building the other rows: the shard of one rank."""
+    flags = (_lib.GCN_ADD_SELF_LOOPS if self_loops else 0) | (0 if scramble else _lib.GCN_RMAT_NATURAL_ORDER)
+    n_keys, ws_bytes = ctypes.c_int64(), ctypes.c_size_t()
+    with torch.cuda.device(device):
+        _lib.call('gcn_rmat_rows_count', scale, edge_factor, seed, flags, row_begin, row_end, ctypes.byref(n_keys),
+                  _stream())
+        _lib.call('gcn_rmat_csr_rows_bound', n_keys.value, ctypes.byref(ws_bytes))
+        indptr = torch.empty(row_end - row_begin + 1, dtype=torch.int64, device=device)
+        indices = torch.empty(max(n_keys.value, 1), dtype=torch.int32, device=device)
+        nnz_out = torch.zeros(1, dtype=torch.int64, device=device)
+        ws = _workspace(ws_bytes.value, indptr.device)
+        _lib.call('gcn_rmat_csr_rows', scale, edge_factor, seed, flags, row_begin, row_end, n_keys.value, _p(indptr),
+                  _p(indices), _p(nnz_out), _p(ws), ws.numel(), _stream())
+        nnz = int(nnz_out.item())
+    del ws
+    return indptr, indices[:nnz].clone()
+
+
+def synthetic_dense(n, f, seed=7, device='cuda', first_row=0):
+    """Rows first_row .. first_row + n - 1 of the seeded synthetic matrix with f columns."""
     out = torch.empty((n, f), dtype=torch.float32, device=device)
-    _lib.call('gcn_fill_synthetic_f32', n * f, seed, _p(out), _stream())
+    _lib.call('gcn_fill_synthetic_range_f32', first_row * f, n * f, seed, _p(out), _stream())
     return out
 
 

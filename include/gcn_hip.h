@@ -145,8 +145,23 @@ int gcn_rmat_csr_bound(int scale, int edge_factor, int flags, int64_t* nnz_capac
 int gcn_rmat_csr(int scale, int edge_factor, uint64_t seed, int flags, int64_t* indptr_out, int32_t* indices_out,
                  int64_t* nnz_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The rows [row_begin, row_end) of the same graph without building the rest: what one rank of a
+ * row-partitioned run holds (column indices stay global; indptr_out has row_end - row_begin + 1
+ * entries and starts at 0).  Equal, bit for bit, to that slice of gcn_rmat_csr's output.
+ *   1. gcn_rmat_rows_count   -> *n_keys_host (host): generated keys of the range, before deduplication [sync]
+ *   2. gcn_rmat_csr_rows_bound(n_keys) -> workspace bytes; indices_out must hold n_keys entries
+ *   3. gcn_rmat_csr_rows(..., n_keys, ...)  [sync] */
+int gcn_rmat_rows_count(int scale, int edge_factor, uint64_t seed, int flags, int64_t row_begin, int64_t row_end,
+                        int64_t* n_keys_host, void* stream);
+int gcn_rmat_csr_rows_bound(int64_t n_keys, size_t* workspace_bytes);
+int gcn_rmat_csr_rows(int scale, int edge_factor, uint64_t seed, int flags, int64_t row_begin, int64_t row_end,
+                      int64_t n_keys, int64_t* indptr_out, int32_t* indices_out, int64_t* nnz_out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* out[i] = (int32(h >> 32) >> 8) * 2^-23 in [-1,1), h = splitmix(key(seed) ^ i). */
 int gcn_fill_synthetic_f32(int64_t count, uint64_t seed, float* out, void* stream);
+/* The elements first .. first + count - 1 of that sequence (a row block of a larger matrix). */
+int gcn_fill_synthetic_range_f32(int64_t first, int64_t count, uint64_t seed, float* out, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Sparse x dense products -- the hot path.                                   *

@@ -63,6 +63,69 @@ def test_two_rank_product_equals_single_gpu(f, tmp_path):
     assert np.array_equal(got, ref)
 
 
+def test_row_range_generation_equals_the_slice_of_the_whole_graph():
+    """Per-rank generation (gcn_rmat_csr_rows, gcn_fill_synthetic_range_f32) against slices of the whole
+    graph and the whole dense operand, bit for bit, for every rank of 2-, 3- and 8-rank splits at scale 18."""
+    from gcn_amd import sparse
+    scale, f = 18, 24
+    n = 1 << scale
+    for scramble in (True, False):
+        indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True, scramble=scramble)
+        for world in (2, 3, 8):
+            edges = [n * r // world for r in range(world + 1)]
+            for r0, r1 in zip(edges, edges[1:]):
+                ip, ix = sparse.rmat_csr_rows(scale, r0, r1, 16, seed=42, self_loops=True, scramble=scramble)
+                k0, k1 = int(indptr[r0]), int(indptr[r1])
+                assert torch.equal(ip, indptr[r0:r1 + 1] - k0)
+                assert torch.equal(ix, indices[k0:k1])
+    plain_ip, plain_ix = sparse.rmat_csr_rows(scale, 1000, 3000, 16, seed=42, self_loops=False)
+    whole_ip, whole_ix = sparse.rmat_csr(scale, 16, seed=42, self_loops=False)
+    assert torch.equal(plain_ix, whole_ix[int(whole_ip[1000]):int(whole_ip[3000])])
+    empty_ip, empty_ix = sparse.rmat_csr_rows(scale, 77, 77, 16, seed=42, self_loops=True)
+    assert empty_ip.tolist() == [0] and empty_ix.numel() == 0
+    b = sparse.synthetic_dense(n, f, seed=7)
+    assert torch.equal(sparse.synthetic_dense(5000, f, seed=7, first_row=12345), b[12345:17345])
+
+
+def _rmat_shard_worker(rank, world, port, result_dir, scale):
+    faulthandler.dump_traceback_later(90, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from gcn_amd import dist as gdist, sparse
+        n = 1 << scale
+        shard = gdist.rmat_shard(scale, 16, rank, world, seed=42)
+        indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+        d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+        vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+        ref = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, rank, world)
+        assert (shard.row_begin, shard.row_end) == (ref.row_begin, ref.row_end)
+        assert torch.equal(shard.local.indptr, ref.local.indptr)
+        assert torch.equal(shard.local.indices, ref.local.indices)
+        assert torch.equal(shard.local.values, ref.local.values)
+        f = 64
+        b_local = sparse.synthetic_dense(shard.row_end - shard.row_begin, f, seed=7, first_row=shard.row_begin)
+        c = gdist.HaloSpmm(shard, f)(b_local)
+        whole = sparse.spmm(sparse.DeviceCSR(n, n, indptr, indices, vals), sparse.synthetic_dense(n, f, seed=7))
+        assert torch.equal(c, whole[shard.row_begin:shard.row_end])
+        open(os.path.join(result_dir, 'ok_%d' % rank), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_generate_their_own_shards(tmp_path):
+    """2 ranks on one GPU at scale 18: each generates only its row block of A_hat (degrees exchanged by
+    all-gather) and its rows of B; shard and product equal the slices of the single-process ones."""
+    world = 2
+    port = 29500 + (os.getpid() % 1000)
+    mp.start_processes(_rmat_shard_worker, args=(world, port, str(tmp_path), 18), nprocs=world, join=True,
+                       start_method='spawn')
+    assert all((tmp_path / ('ok_%d' % r)).exists() for r in range(world))
+
+
 def _single_rank_rccl_worker(rank, port, result_dir):
     faulthandler.dump_traceback_later(90, exit=True)
     sys.path.insert(0, ROOT)
