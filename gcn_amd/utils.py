@@ -171,19 +171,63 @@ def adjacency_from_dict_of_lists(keys, ptr, nbr):
 
 
 def preprocess_features(features, feature_type):
-    """gcn/utils.py:278-294.  'bow': row-normalise (r_inv = rowsum^-1, inf -> 0); 'none': identity
-    features.  'tfidf' needs scikit-learn's transformer and is not part of this build."""
-    if feature_type == 'bow':
-        rowsum = np.array(features.sum(1))
-        with np.errstate(divide='ignore'):
-            r_inv = np.power(rowsum, -1).flatten()
-        r_inv[np.isinf(r_inv)] = 0.
-        features = sp.diags(r_inv).dot(features)
-    elif feature_type == 'none':
-        features = sp.csr_matrix(sp.eye(features.shape[0]))
-    else:
+    """Feature preprocessing of gcn/utils.py:278-294: 'bow' scales every row by the reciprocal of its sum
+    (a row that sums to zero stays zero); 'none' replaces the features by the identity.  'tfidf' needs
+    scikit-learn's transformer and is not part of this build."""
+    if feature_type == 'none':
+        return sp.csr_matrix(sp.eye(features.shape[0]))
+    if feature_type != 'bow':
         raise ValueError('Invalid feature type: ' + str(feature_type))
-    return features
+    totals = np.asarray(features.sum(axis=1)).ravel()
+    with np.errstate(divide='ignore'):
+        scale = np.where(totals != 0, np.power(totals, -1.0), 0.0)
+    return sp.diags(scale).dot(features)
+
+
+def _take_rows(matrix, source_rows):
+    """Row gather of a CSR matrix: row i of the result is row source_rows[i] of ``matrix``."""
+    return sp.csr_matrix(matrix)[source_rows]
+
+
+def _spread_rows(block, positions, n_rows):
+    """A float64 matrix of ``n_rows`` rows holding row k of ``block`` at row positions[k], zeros elsewhere
+    (the reference pads into a default-typed, i.e. float64, matrix: CiteSeer's features come out float64)."""
+    coo = sp.coo_matrix(block)
+    return sp.csr_matrix((coo.data.astype(np.float64), (positions[coo.row], coo.col)),
+                         shape=(n_rows, block.shape[1]))
+
+
+class Split(object):
+    """The reference's random split (gcn/utils.py:183-237) computed from positions in the shuffled order.
+
+    The reference walks the shuffled node order and takes a node for training while its class still
+    needs members, until every class holds ``per_class``; the walk's end is the cursor after which
+    validation and test nodes are taken.  Walking is not needed: a node is taken exactly when it is among
+    the first ``per_class`` of its class in that order, and the cursor sits just behind the node that
+    completes the last class (at the end when some class never fills up)."""
+
+    def __init__(self, labels, order, per_class):
+        member = labels[order] != 0                                  # [position, class]
+        seen = np.cumsum(member, axis=0)                             # members of each class up to a position
+        taken_pos, taken_cls = np.nonzero(member & (seen <= per_class))
+        self.train = order[taken_pos]                                # position order; a multi-label row once per class
+        if per_class <= 0 or member.shape[0] == 0:
+            self.cursor = 0
+        else:
+            complete = np.all(seen >= per_class, axis=1)
+            self.cursor = int(np.argmax(complete)) + 1 if complete.any() else len(order)
+        self.order = order
+
+    def validation_and_test(self, validate, validation_size, test_size):
+        order, cursor, n = self.order, self.cursor, len(self.order)
+        tail = order[n - test_size:] if test_size else None
+        if validate:
+            assert cursor + validation_size + (test_size or 0) < n, 'not enough nodes left for validation and test'
+            return order[cursor:cursor + validation_size], (tail if test_size else order[cursor + validation_size:])
+        if test_size:
+            assert cursor + test_size < n, 'not enough nodes left for the test set'
+            return tail, tail
+        return order[cursor:], order[cursor:]
 
 
 def load_data(dataset_str, train_size, validation_size, model_config, shuffle=True, data_dir=None):
@@ -191,80 +235,54 @@ def load_data(dataset_str, train_size, validation_size, model_config, shuffle=Tr
 
     The files are the reference's ``ind.<dataset>.*`` contents re-encoded as arrays in
     ``data/<dataset>_raw.npz``.  Returns ``adj, features, y_train, y_val, y_test, train_mask,
-    val_mask, test_mask`` exactly as the reference does; uses numpy's global RandomState for the
-    shuffle, so ``np.random.seed(seed)`` beforehand reproduces the reference's split."""
+    val_mask, test_mask`` as the reference does.  The node order is shuffled with numpy's global
+    RandomState (one ``np.random.shuffle`` of ``arange(n)``, the reference's only draw), so
+    ``np.random.seed(seed)`` beforehand reproduces the reference's split for that seed."""
     global all_labels
     path = os.path.join(data_dir or DATA_DIR, dataset_str + '_raw.npz')
     if not os.path.exists(path):
         raise ValueError('dataset "%s" is not available (%s missing)' % (dataset_str, path))
     raw = np.load(path)
 
-    def csr(part):
-        return sp.csr_matrix((raw[part + '_data'], raw[part + '_indices'], raw[part + '_indptr']),
-                             shape=tuple(raw[part + '_shape']))
+    def part(name):
+        return sp.csr_matrix((raw[name + '_data'], raw[name + '_indices'], raw[name + '_indptr']),
+                             shape=tuple(raw[name + '_shape']))
 
-    x, tx, allx = csr('x'), csr('tx'), csr('allx')
-    y, ty, ally = raw['y'].astype(np.int32), raw['ty'].astype(np.int32), raw['ally'].astype(np.int32)
     adj = adjacency_from_dict_of_lists(raw['graph_keys'], raw['graph_ptr'], raw['graph_nbr'])
-    test_idx_reorder = raw['test_index'].tolist()
-    test_idx_range = np.sort(test_idx_reorder)
-
-    if dataset_str == 'citeseer':
-        # isolated test nodes become zero rows at the right position (utils.py:127-136)
-        full = range(min(test_idx_reorder), max(test_idx_reorder) + 1)
-        tx_extended = sp.lil_matrix((len(full), x.shape[1]))
-        tx_extended[test_idx_range - min(test_idx_range), :] = tx
-        tx = tx_extended
-        ty_extended = np.zeros((len(full), y.shape[1]))
-        ty_extended[test_idx_range - min(test_idx_range), :] = ty
-        ty = ty_extended
-
-    features = sp.vstack((allx, tx)).tolil()
-    labels = np.vstack((ally, ty))
-    features[test_idx_reorder, :] = features[test_idx_range, :]
-    labels[test_idx_reorder, :] = labels[test_idx_range, :]
-    features = preprocess_features(features, feature_type=model_config['feature'])
+    test_ids = raw['test_index'].astype(np.int64)                    # node ids of the test rows, in file order
+    test_sorted = np.sort(test_ids)
+    test_x, test_y = part('tx'), raw['ty'].astype(np.int32)
+    span = int(test_sorted[-1] - test_sorted[0]) + 1
+    if span != test_x.shape[0]:
+        # ids missing from the test range (CiteSeer's isolated nodes, utils.py:127-136) become zero rows
+        at = test_sorted - test_sorted[0]
+        test_x = _spread_rows(test_x, at, span)
+        padded = np.zeros((span, test_y.shape[1]))
+        padded[at] = test_y
+        test_y = padded
+    stacked_x = sp.vstack((part('allx'), test_x)).tocsr()
+    stacked_y = np.vstack((raw['ally'].astype(np.int32), test_y))
+    # the test rows are stored in file order: move each to the row of its node id (utils.py:175-176)
+    source = np.arange(stacked_y.shape[0])
+    source[test_ids] = test_sorted
+    labels = stacked_y[source]
+    features = preprocess_features(_take_rows(stacked_x, source).tolil(), feature_type=model_config['feature'])
     all_labels = labels.copy()
 
-    # split (utils.py:183-215): walk a shuffled order, take nodes until every class has train_size
-    idx = np.arange(len(labels))
-    no_class = labels.shape[1]
-    label_each_class = [train_size for _ in range(no_class)]
+    order = np.arange(labels.shape[0])
     if shuffle:
-        np.random.shuffle(idx)
-    idx_train = []
-    count = [0 for _ in range(no_class)]
-    nxt = 0
-    for i in idx:
-        if count == label_each_class:
-            break
-        nxt += 1
-        for j in range(no_class):
-            if labels[i, j] and count[j] < label_each_class[j]:
-                idx_train.append(i)
-                count[j] += 1
+        np.random.shuffle(order)
+    split = Split(labels, order, train_size)
+    held_out_val, held_out_test = split.validation_and_test(model_config['validate'], validation_size,
+                                                            model_config['test_size'])
+    print('labels of each class : ', np.sum(labels[split.train], axis=0))
 
-    test_size = model_config['test_size']
-    if model_config['validate']:
-        if test_size:
-            assert nxt + validation_size < len(idx)
-        idx_val = idx[nxt:nxt + validation_size]
-        assert nxt + validation_size + (test_size or 0) < len(idx)
-        idx_test = idx[-test_size:] if test_size else idx[nxt + validation_size:]
-    else:
-        if test_size:
-            assert nxt + test_size < len(idx)
-        idx_val = idx[-test_size:] if test_size else idx[nxt:]
-        idx_test = idx[-test_size:] if test_size else idx[nxt:]
-    print('labels of each class : ', np.sum(labels[idx_train], axis=0))
+    def masked(nodes):
+        mask = sample_mask(nodes, labels.shape[0])
+        y = np.zeros(labels.shape)
+        y[mask] = labels[mask]
+        return y, mask
 
-    train_mask = sample_mask(idx_train, labels.shape[0])
-    val_mask = sample_mask(idx_val, labels.shape[0])
-    test_mask = sample_mask(idx_test, labels.shape[0])
-    y_train = np.zeros(labels.shape)
-    y_val = np.zeros(labels.shape)
-    y_test = np.zeros(labels.shape)
-    y_train[train_mask, :] = labels[train_mask, :]
-    y_val[val_mask, :] = labels[val_mask, :]
-    y_test[test_mask, :] = labels[test_mask, :]
+    (y_train, train_mask), (y_val, val_mask), (y_test, test_mask) = (masked(split.train), masked(held_out_val),
+                                                                     masked(held_out_test))
     return adj, features, y_train, y_val, y_test, train_mask, val_mask, test_mask
