@@ -44,6 +44,28 @@ def default_model_config():
     return d
 
 
+# What of the reference's configuration space this build runs: the GCN propagation path only.
+SUPPORTED = {
+    'Model': ('GCN',),                                              # not: cotraining, selftraining, lp, union, intersection
+    'conv': ('gcn', 'gcn_rw', 'gcn_unnorm', 'gcn_noloop'),          # not: cheby, chebytheta
+    'feature': ('bow', 'none'),                                     # not: tfidf
+    'connection': ('c',),                                           # not: f (dense), d (DenseNet), r (residual), C
+}
+
+
+def check_supported(model_config):
+    """Refuse, while the configuration is being read, what the reference accepts and this build does not
+    run -- instead of failing later inside train()."""
+    for key in ('Model', 'conv', 'feature'):
+        if model_config[key] not in SUPPORTED[key]:
+            raise ValueError('%s = %r is outside this build (the GCN propagation path): supported values are %s'
+                             % (key, model_config[key], ', '.join(map(repr, SUPPORTED[key]))))
+    for letter in model_config['connection']:
+        if letter not in SUPPORTED['connection']:
+            raise ValueError('connection letter %r is outside this build: only graph-convolution layers ("c") run here'
+                             % letter)
+
+
 def build_parser():
     parser = argparse.ArgumentParser(description=(
         'Train and test a Graph Convolution Network for node classification on the MI355X path.\n'
@@ -79,6 +101,7 @@ def load_configuration(argv=None, echo=True):
         model_config = deepcopy(configuration['default'])
         model_config.update(model)
         preprocess_model_config(model_config)
+        check_supported(model_config)
         merged.append(model_config)
     configuration['model_list'] = merged
     return configuration, args

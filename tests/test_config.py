@@ -40,3 +40,20 @@ def test_flags_override_as_in_the_reference():
     assert conf['model_list'][0]['train_size'] == [5] * 7
     # the name is generated from the architecture when none is given (gcn/utils.py preprocess_model_config)
     assert conf['model_list'][0]['name']
+
+
+def test_values_outside_the_build_are_refused_when_the_configuration_is_read():
+    import pytest
+    import config
+    cfg = config.default_model_config()
+    cfg.update({'Model': 'GCN', 'connection': ['c', 'c']})
+    config.check_supported(cfg)
+    for key, value in (('Model', 'cotraining'), ('Model', 'lp'), ('conv', 'cheby'), ('feature', 'tfidf')):
+        bad = dict(cfg)
+        bad[key] = value
+        with pytest.raises(ValueError, match='outside this build'):
+            config.check_supported(bad)
+    bad = dict(cfg)
+    bad['connection'] = ['c', 'f']
+    with pytest.raises(ValueError, match='connection letter'):
+        config.check_supported(bad)
