@@ -60,6 +60,7 @@ SIGNATURES = {
     'gcn_spmm_plan_create_split': [_i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_vp), _vp],
     'gcn_spmm_plan_destroy': [_vp],
     'gcn_spmm_plan_set_hot_columns': [_vp, _i64],
+    'gcn_spmm_plan_set_lds_hub_rows': [_vp, _i64],
     'gcn_spmm_plan_info': [_vp, _pi64],
     'gcn_spmm_plan_workspace_bytes': [_vp, _i64, _psz],
     'gcn_spmm_plan_set_timing': [_vp, _int],

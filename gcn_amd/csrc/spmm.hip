@@ -41,6 +41,10 @@ struct gcn_spmm_plan {
     // columns >= hot_cols are loaded with the non-temporal hint by the wave-per-row instances (0: off).
     // After a degree-descending relabel the first columns are the hub rows of B: the rows worth caching.
     int64_t hot_cols;
+    // narrow products stage the first lds_hub_rows rows of B in LDS, once per workgroup, and entries whose
+    // column is below that number read them from there (0: off).  For a degree-ordered matrix those are the
+    // hub rows: the "LDS-staged row-block" form of the product.
+    int64_t lds_hub_rows;
     int timing;           // record events around the kernels of every product
     hipEvent_t ev[3];     // start, after the row kernel, after the long-row reduction
 };
@@ -98,6 +102,9 @@ constexpr int kUnroll = 4;       // entries in flight per lane group
 // batch (same order of additions, same bits; the extra loads of short rows hit the clamped, cached
 // address).  Cora, F = 16: 29 -> 12 us per product.
 constexpr int kUnrollSmall = 16;
+// LDS a workgroup of a narrow product may fill with hub rows of B: 32 KiB leaves room for five
+// workgroups per CU, the number the kernel's registers allow
+constexpr int64_t kHubLdsBytes = 32 * 1024;
 
 // ------------------------------------------------------------------------------------------------
 // plan kernels
@@ -458,13 +465,16 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
 //    dependent memory latencies instead of one.
 //  - Row pointers come from a register window (indptr of 64 consecutive rows, one per lane, read with
 //    a cross-lane shuffle), not from memory at claim time.
-template <int LPR, int VEC, int VPL, bool DROPOUT, int kUnroll>
+//  - HUBS: the first `hub_rows` rows of B (f columns each, row-major) sit in LDS at `hub_lds`; an entry whose
+//    column is below hub_rows takes its row from there instead of from memory.
+template <int LPR, int VEC, int VPL, bool DROPOUT, int kUnroll, bool HUBS = false>
 __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, const int32_t* __restrict__ strip_row,
                                             const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                             const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                             uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
                                             const DropArgs& dr, int split, const float* __restrict__ add,
-                                            int64_t ldadd, int64_t nnz, const OutDrop& od) {
+                                            int64_t ldadd, int64_t nnz, const OutDrop& od,
+                                            const float* hub_lds = nullptr, uint32_t hub_rows = 0) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
@@ -583,8 +593,14 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     const float* brow = b + (uint64_t)cidx[u] * (uint64_t)ldb;
+                    if (HUBS && cidx[u] < hub_rows) {
+                        const float* hrow = hub_lds + cidx[u] * (uint32_t)f;
 #pragma unroll
-                    for (int v = 0; v < VPL; ++v) load_vec<VEC>(brow + lcol[v], bv[u][v]);
+                        for (int v = 0; v < VPL; ++v) load_vec<VEC>(hrow + lcol[v], bv[u][v]);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < VPL; ++v) load_vec<VEC>(brow + lcol[v], bv[u][v]);
+                    }
                 }
                 float a_now[kUnroll];
                 bool kept[kUnroll];
@@ -687,6 +703,7 @@ struct PlanView {
     int split;
     int chunk_len;
     uint32_t hot_cols;
+    uint32_t lds_hub_rows;
     const int32_t* strip_row;
     const int32_t* chunk_long;
     const int32_t* long_row;
@@ -695,7 +712,7 @@ struct PlanView {
 
 // The whole product in one launch: the blocks that sum chunks of long rows come first (they are
 // the longest work items), the strip blocks after them.
-template <int LPR, int VEC, int VPL, bool DROPOUT, int U, bool NT = false>
+template <int LPR, int VEC, int VPL, bool DROPOUT, int U, bool NT = false, bool HUBS = false>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const int64_t* __restrict__ indptr,
                                                            const int32_t* __restrict__ indices,
                                                            const float* __restrict__ vals, int64_t f,
@@ -714,7 +731,21 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
         strips_block<LPR, VEC, VPL, DROPOUT, (U > kUnroll), NT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row,
                                                                 indptr, indices, vals, f, b, ldb, c, ldc, relu, dr,
                                                                 pv.split, add, ldadd, od, pv.hot_cols);
-    else
+    else if (HUBS) {
+        // stage rows 0 .. lds_hub_rows-1 of B: f is a multiple of 4 and the rows are 16-byte aligned (VEC == 4)
+        extern __shared__ float4 hub_stage[];
+        const uint32_t quads_per_row = (uint32_t)f / 4;
+        const uint32_t quads = pv.lds_hub_rows * quads_per_row;
+        for (uint32_t q = threadIdx.x; q < quads; q += kBlock) {
+            const uint32_t row = q / quads_per_row, quad = q - row * quads_per_row;
+            hub_stage[q] = *reinterpret_cast<const float4*>(b + (uint64_t)row * ldb + 4 * quad);
+        }
+        __syncthreads();
+        slots_block<LPR, VEC, VPL, DROPOUT, U, true>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr,
+                                                     indices, vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd,
+                                                     pv.nnz, od, reinterpret_cast<const float*>(hub_stage),
+                                                     pv.lds_hub_rows);
+    } else
         slots_block<LPR, VEC, VPL, DROPOUT, U>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
                                             vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd, pv.nnz, od);
 }
@@ -832,6 +863,20 @@ static int launch_variant(const SpmmCall& a) {
         if (p->hot_cols > 0 && p->hot_cols < p->n_cols) {
             pv.hot_cols = (uint32_t)p->hot_cols;
             spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U, true><<<(unsigned)grid, kBlock, 0, a.st>>>(
+                pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add,
+                a.ldadd, a.od);
+            launched = true;
+        }
+    }
+    pv.lds_hub_rows = 0;
+    if constexpr (LPR <= 16 && VEC == 4 && VPL == 1 && !DROPOUT && U == kUnroll) {
+        // rows of B that fit kHubLdsBytes of LDS per workgroup, and exist, and are covered by one pass
+        const int64_t fit = kHubLdsBytes / (a.f * (int64_t)sizeof(float));
+        const int64_t hubs = std::min<int64_t>(std::min<int64_t>(p->lds_hub_rows, fit), p->n_cols);
+        if (hubs > 0 && a.f % 4 == 0 && a.f <= LPR * VEC) {
+            pv.lds_hub_rows = (uint32_t)hubs;
+            const size_t lds_bytes = (size_t)hubs * (size_t)a.f * sizeof(float);
+            spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U, false, true><<<(unsigned)grid, kBlock, lds_bytes, a.st>>>(
                 pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add,
                 a.ldadd, a.od);
             launched = true;
@@ -973,6 +1018,7 @@ int gcn_spmm_plan_create_split(int64_t n_rows, int64_t n_cols, int64_t nnz, cons
     }
     p->timing = 0;
     p->hot_cols = 0;
+    p->lds_hub_rows = 0;
     p->ev[0] = p->ev[1] = p->ev[2] = nullptr;
     int32_t* d_rows = nullptr;
     int64_t *d_starts = nullptr, *d_ends = nullptr;
@@ -1110,6 +1156,12 @@ int gcn_spmm_plan_last_timing(const gcn_spmm_plan* plan, float* ms2) {
 int gcn_spmm_plan_set_hot_columns(gcn_spmm_plan* plan, int64_t hot_cols) {
     if (!plan || hot_cols < 0) return fail(GCN_ERR_BAD_ARG, "bad argument");
     plan->hot_cols = hot_cols;
+    return GCN_OK;
+}
+
+int gcn_spmm_plan_set_lds_hub_rows(gcn_spmm_plan* plan, int64_t hub_rows) {
+    if (!plan || hub_rows < 0) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    plan->lds_hub_rows = hub_rows;
     return GCN_OK;
 }
 

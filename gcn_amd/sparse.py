@@ -68,6 +68,10 @@ class SpmmPlan(object):
         """Rows of B from column ``hot_cols`` on are loaded non-temporally by wide products (0: off)."""
         _lib.call('gcn_spmm_plan_set_hot_columns', self.handle, int(hot_cols))
 
+    def set_lds_hub_rows(self, hub_rows):
+        """Narrow products keep the first ``hub_rows`` rows of B (as many as fit 32 KiB) in LDS (0: off)."""
+        _lib.call('gcn_spmm_plan_set_lds_hub_rows', self.handle, int(hub_rows))
+
     def set_timing(self, enable=True):
         """Record HIP events around the kernels of every product on this plan."""
         _lib.call('gcn_spmm_plan_set_timing', self.handle, 1 if enable else 0)

@@ -189,6 +189,12 @@ int gcn_spmm_plan_destroy(gcn_spmm_plan* plan);
  * (default) turns the hint off.  Results do not change.  No counterpart in the reference (its kernel,
  * gcn/layers.py:31, runs on a CPU). */
 int gcn_spmm_plan_set_hot_columns(gcn_spmm_plan* plan, int64_t hot_cols);
+/* LDS-staged hub rows for narrow products (f <= 64, f a multiple of 4) with this plan: every workgroup
+ * copies the first min(hub_rows, 32 KiB / (4 f)) rows of B into LDS and entries whose column index is below
+ * that number read their row from LDS instead of memory.  Meant for a matrix relabelled by
+ * gcn_degree_order, whose first columns are the hubs (the rows selected by degree); 0 (default): off.
+ * Same additions in the same order: results do not change.  No counterpart in the reference. */
+int gcn_spmm_plan_set_lds_hub_rows(gcn_spmm_plan* plan, int64_t hub_rows);
 /* host-side facts about a plan: what[0]=n_strips, [1]=rows longer than the split threshold, [2]=their
  * chunks, [3]=the split threshold (the smallest one: rows up to it are summed serially for every width) */
 int gcn_spmm_plan_info(const gcn_spmm_plan* plan, int64_t* what4);

@@ -162,3 +162,33 @@ def test_scale_22_width_512_properties(oracle):
     assert float((s[:, 0].double() - row_sum).abs().max()) <= REL_TOL * float(row_sum.abs().max())
     del a
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('f', [4, 8, 12, 16, 32, 64])
+def test_lds_staged_hub_rows_change_no_bit(big_hat, oracle, f):
+    """The LDS-staged form of a narrow product (gcn_spmm_plan_set_lds_hub_rows) on the degree-ordered
+    matrix: hub rows of B served from LDS, the same additions in the same order -- identical bits to the
+    plain form, which is itself checked against the oracle on the same matrix."""
+    import torch
+    from gcn_amd import sparse
+    n, a, ip, ix, v = big_hat
+    new_id, old_id = sparse.degree_order(a.indptr)
+    r_ip, r_ix, r_v = sparse.csr_relabel(n, n, a.indptr, a.indices, a.values.double(), new_id, new_id)
+    ordered = sparse.DeviceCSR(n, n, r_ip, r_ix.contiguous(), r_v.to(torch.float32))
+    b = sparse.synthetic_dense(n, f, seed=21)
+    plain = sparse.spmm(ordered, b)
+    ref32 = oracle.spmm_csr(r_ip.cpu().numpy(), r_ix.cpu().numpy(), ordered.values.cpu().numpy(), b.cpu().numpy(),
+                            threads=8)
+    short = np.diff(r_ip.cpu().numpy()) <= 256
+    assert np.array_equal(plain.cpu().numpy()[short], ref32[short])
+    for hubs in (1, 100, 512, 1 << 20):                    # more than fit: clipped to 32 KiB of rows
+        ordered.plan.set_lds_hub_rows(hubs)
+        assert torch.equal(sparse.spmm(ordered, b), plain)
+        assert torch.equal(sparse.spmm(ordered, b, relu=True), torch.clamp(plain, min=0))
+    ordered.plan.set_lds_hub_rows(0)
+    # a strided operand (row pitch wider than f) stages the same rows
+    wide = torch.zeros((n, f + 4), device='cuda')
+    wide[:, :f] = b
+    ordered.plan.set_lds_hub_rows(256)
+    assert torch.equal(sparse.spmm(ordered, wide[:, :f]), plain)
+    ordered.plan.set_lds_hub_rows(0)

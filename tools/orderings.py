@@ -65,6 +65,10 @@ def main():
     ap.add_argument('--hot', default='0', help='comma list of hot-column counts (0 = hint off)')
     ap.add_argument('--fold', default='', help='comma list of M: column indices taken modulo M, B has M rows')
     ap.add_argument('--halves', action='store_true', help='also the product as two passes over 128 columns each')
+    ap.add_argument('--lds-hubs', default='', help='comma list of hub-row counts staged in LDS (narrow widths)')
+    ap.add_argument('--slabs', type=int, default=0,
+                    help='also the product as passes over column tiles of this many columns (the narrow kernel), '
+                         'without and with the --lds-hubs rows staged')
     ap.add_argument('--reps', type=int, default=5)
     args = ap.parse_args()
     n, f = 1 << args.scale, args.features
@@ -79,6 +83,28 @@ def main():
             med, best = time_product(a, b, c, args.reps)
             print(json.dumps(dict(base, variant='full width', hot_cols=hot, ms_median=med, ms_min=best)), flush=True)
         a.plan.set_hot_columns(0)
+        for hubs in (int(x) for x in args.lds_hubs.split(',') if x):
+            a.plan.set_lds_hub_rows(hubs)
+            med, best = time_product(a, b, c, args.reps)
+            print(json.dumps(dict(base, variant='hub rows in LDS', lds_hub_rows=hubs, ms_median=med, ms_min=best)),
+                  flush=True)
+        a.plan.set_lds_hub_rows(0)
+        if args.slabs:
+            for hubs in [0] + [int(x) for x in args.lds_hubs.split(',') if x]:
+                a.plan.set_lds_hub_rows(hubs)
+                a.plan.set_timing(True)
+                ms = []
+                for _ in range(args.reps + 1):
+                    t = 0.0
+                    for c0 in range(0, f, args.slabs):
+                        sparse.spmm(a, b[:, c0:c0 + args.slabs], out=c[:, c0:c0 + args.slabs])
+                        t += sum(a.plan.last_timing())
+                    ms.append(t)
+                a.plan.set_timing(False)
+                ms = sorted(ms[1:])
+                print(json.dumps(dict(base, variant='column tiles of %d' % args.slabs, lds_hub_rows=hubs,
+                                      ms_median=ms[len(ms) // 2], ms_min=ms[0])), flush=True)
+            a.plan.set_lds_hub_rows(0)
         if args.halves:
             a.plan.set_timing(True)
             ms = []
