@@ -14,6 +14,7 @@ GCN_ERR_BAD_ARG = 1
 GCN_ERR_INDEX_RANGE = 2
 GCN_ERR_HIP = 3
 GCN_ERR_WORKSPACE = 4
+GCN_ERR_RCCL = 5
 
 GCN_ADD_SELF_LOOPS = 1
 GCN_BINARY = 2
@@ -80,6 +81,11 @@ SIGNATURES = {
     'gcn_gemm_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp],
     'gcn_gemm_tn_workspace_bytes': [_i64, _i64, _i64, ctypes.POINTER(ctypes.c_size_t)],
     'gcn_gather_rows_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp],
+    'gcn_comm_unique_id': [_vp],
+    'gcn_comm_init_rank': [ctypes.POINTER(_vp), _int, _vp, _int],
+    'gcn_comm_destroy': [_vp],
+    'gcn_allgather_rows_f32': [_vp, _vp, _vp, _i64, _i64, _vp],
+    'gcn_exchange_rows_f32': [_vp, _vp, _pi64, _vp, _pi64, _i64, _vp],
     'gcn_softmax_xent_f32': [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _vp],
     'gcn_loss_summary_workspace_bytes': [_i64, _i64, ctypes.POINTER(ctypes.c_size_t)],
     'gcn_loss_summary_f32': [_i64, _vp, _i64, _vp, _f32, _vp, _sz, _vp, _vp],

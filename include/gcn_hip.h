@@ -33,7 +33,8 @@ typedef enum {
     GCN_ERR_BAD_ARG = 1,      /* Python: ValueError   (reference: ValueError at train.py:141, utils.py:293) */
     GCN_ERR_INDEX_RANGE = 2,  /* Python: ValueError   (TensorFlow: InvalidArgumentError for out-of-range sparse indices) */
     GCN_ERR_HIP = 3,          /* Python: RuntimeError */
-    GCN_ERR_WORKSPACE = 4     /* Python: ValueError   (workspace too small) */
+    GCN_ERR_WORKSPACE = 4,    /* Python: ValueError   (workspace too small) */
+    GCN_ERR_RCCL = 5          /* Python: RuntimeError (RCCL missing or a collective failed) */
 } gcn_status;
 
 /* flags of gcn_coo_to_csr */
@@ -326,6 +327,29 @@ int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda
  * value in [0, n_src_rows) -- not checked. */
 int gcn_gather_rows_f32(int64_t n_out, int64_t f, int64_t n_src_rows, const float* src, int64_t ld_src,
                         const int64_t* rows, float* dst, int64_t ld_dst, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Exchange step of the row-partitioned product (one process per GPU).        *
+ * The reference is single-process (its only parallelism knob is               *
+ * intra_op_parallelism_threads, train.py:276-277), so these have no           *
+ * counterpart there; the dense operand they move is the `pre_sup` of          *
+ * gcn/layers.py:198-202.  RCCL is opened at the first call.                   *
+ * ------------------------------------------------------------------------- */
+
+/* A 128-byte communicator id (host buffer) made by one rank and handed to the others by the caller. */
+int gcn_comm_unique_id(void* id128_host);
+/* This process's rank of an n_ranks communicator on the CURRENT device (collective over the ranks). */
+int gcn_comm_init_rank(void** comm_out, int n_ranks, const void* id128_host, int rank);
+int gcn_comm_destroy(void* comm);
+
+/* recv [n_ranks * rows_per_rank x f] = the send blocks [rows_per_rank x f] of all ranks in rank order:
+ * the all-gather of the per-layer dense matrix; both buffers contiguous row-major. */
+int gcn_allgather_rows_f32(void* comm, const float* send, float* recv, int64_t rows_per_rank, int64_t f, void* stream);
+/* Exchange of the referenced rows only: send holds, rank after rank, send_rows_host[p] rows of f floats
+ * for rank p; recv receives recv_rows_host[p] rows from rank p, rank after rank (host arrays of n_ranks
+ * counts).  One grouped send/receive pair per peer, so every xGMI link carries its own pair at once. */
+int gcn_exchange_rows_f32(void* comm, const float* send, const int64_t* send_rows_host, float* recv,
+                          const int64_t* recv_rows_host, int64_t f, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Loss and optimiser of the training step.                                   *

@@ -170,6 +170,49 @@ def test_exchange_in_flight_over_rccl(tmp_path):
     assert (tmp_path / 'ok').exists()
 
 
+def _abi_comm_worker(rank, result_dir):
+    faulthandler.dump_traceback_later(90, exit=True)
+    sys.path.insert(0, ROOT)
+    import ctypes
+    torch.cuda.set_device(0)
+    from gcn_amd import _lib, sparse
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    uid = ctypes.create_string_buffer(128)
+    _lib.call('gcn_comm_unique_id', uid)
+    comm = ctypes.c_void_p()
+    _lib.call('gcn_comm_init_rank', ctypes.byref(comm), 1, uid, 0)
+    assert comm.value
+    n, f = 5000, 64
+    b = sparse.synthetic_dense(n, f, seed=7)
+    gathered = torch.full((n, f), float('nan'), device='cuda')
+    _lib.call('gcn_allgather_rows_f32', comm, b.data_ptr(), gathered.data_ptr(), n, f, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(gathered, b)
+    # the referenced-rows exchange with oneself: 700 packed rows out, the same 700 rows in
+    rows = torch.arange(0, 4900, 7, device='cuda')
+    send = torch.empty((rows.numel(), f), device='cuda')
+    sparse.gather_rows(b, rows, send)
+    recv = torch.full((rows.numel(), f), float('nan'), device='cuda')
+    counts = (ctypes.c_int64 * 1)(rows.numel())
+    _lib.call('gcn_exchange_rows_f32', comm, send.data_ptr(), counts, recv.data_ptr(), counts, f, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(recv, b[rows])
+    # zero rows and bad arguments
+    zero = (ctypes.c_int64 * 1)(0)
+    _lib.call('gcn_exchange_rows_f32', comm, None, zero, None, zero, f, stream)
+    with pytest.raises(ValueError):
+        _lib.call('gcn_allgather_rows_f32', None, b.data_ptr(), gathered.data_ptr(), n, f, stream)
+    _lib.call('gcn_comm_destroy', comm)
+    open(os.path.join(result_dir, 'ok'), 'w').write('ok')
+
+
+def test_rccl_entry_points_of_the_c_abi(tmp_path):
+    """gcn_comm_* / gcn_allgather_rows_f32 / gcn_exchange_rows_f32 through ctypes alone (no
+    torch.distributed) on a 1-rank communicator, the only RCCL world one GPU allows."""
+    mp.start_processes(_abi_comm_worker, args=(str(tmp_path),), nprocs=1, join=True, start_method='spawn')
+    assert (tmp_path / 'ok').exists()
+
+
 def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first):
     if world > 1:
         faulthandler.dump_traceback_later(90, exit=True)
