@@ -49,6 +49,8 @@ def parse_args():
                     help='N > 1: all-gather the whole of B instead of exchanging only the referenced rows')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
                     help='development only: every rank uses cuda:0 and the gloo backend')
+    ap.add_argument('--single-rank-collectives', action='store_true',
+                    help='development only: one rank, but through the N-rank code path over RCCL (1-rank communicator)')
     ap.add_argument('--cpu-row-stride', type=int, default=16,
                     help='the CPU baseline multiplies every k-th row of the same matrix')
     return ap.parse_args()
@@ -258,9 +260,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    sharded = world > 1 or args.single_rank_collectives
+    if sharded:
         import torch.distributed as dist
-        if args.rehearse_on_one_gpu:
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29433')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        elif args.rehearse_on_one_gpu:
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
@@ -270,7 +277,7 @@ def main():
     n = 1 << args.scale
     f = args.features
 
-    if world == 1:
+    if not sharded:
         indptr, indices, vals = build_graph(args.scale, args.edge_factor)
         nnz = int(indices.numel())
         b_full = sparse.synthetic_dense(n, f, seed=7)
@@ -302,7 +309,7 @@ def main():
             op(b_local)
 
     def barrier():
-        if world > 1:
+        if sharded:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -316,7 +323,7 @@ def main():
         kernel_ms.append(a.plan.last_timing())          # waits for this step's kernels (per-step event read)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -331,7 +338,7 @@ def main():
         # the row kernel of THIS rank: its shard of the rows against the whole of B
         # (pipelined over column ranges, the events bracket the launch of the last range)
         f_launch = f
-        if world > 1 and not args.allgather:
+        if sharded and not args.allgather:
             lo, hi = op.ranges[-1]
             f_launch = hi - lo
         local_min = bytes_min(a.n_rows, a.n_cols, a.nnz, f_launch)
@@ -343,7 +350,7 @@ def main():
             'config': {'workload': 'A_hat.B, R-MAT scale %d edge factor %d (+I, sym-normalised), F=%d'
                                    % (args.scale, args.edge_factor, f),
                        'n_nodes': n, 'nnz': nnz, 'features': f,
-                       'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B pipelined over column ranges %s' % (op.ranges,))) if world > 1 else 'single GPU'},
+                       'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B pipelined over column ranges %s' % (op.ranges,))) if sharded else 'single GPU'},
             'pct_of_hbm_peak': 100.0 * value / (HBM_PEAK_GBPS * world),
             'gather_gbps': total_gather / (ms_per_step * 1e-3) / 1e9,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -351,14 +358,14 @@ def main():
                          'traffic': None,
                          'kernel': 'spmm_rows_kernel', 'kernel_ms': row_ms, 'reduce_kernel_ms': red_ms,
                          'algorithmic_bytes': local_min, 'launch_features': f_launch},
-            'pipeline_candidates_ms': ([{'ranges': r, 'ms': t} for r, t in tuned] if (world > 1 and tuned) else None),
+            'pipeline_candidates_ms': ([{'ranges': r, 'ms': t} for r, t in tuned] if (sharded and tuned) else None),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             base, allcores, check = cpu_baseline(a, b_full, c, args.cpu_row_stride)
             line['cpu_baseline'] = base
             line['cpu_baseline_all_cores'] = allcores
             line['parity_sample'] = check
-        if world == 1 and not args.no_epoch:
+        if not sharded and not args.no_epoch:
             line['gcn_epoch'] = []
             for name, recorded in (('cora', False), ('citeseer', False), ('cora', True), ('citeseer', True)):
                 try:
@@ -371,7 +378,7 @@ def main():
             line['roofline']['traffic'] = rec['l2_miss_bytes_per_launch']
             line['roofline']['traffic_source'] = rec['source']
             line['l2_miss_traffic_gbps'] = rec['l2_miss_bytes_per_launch'] / (row_ms * 1e-3) / 1e9
-    ranges_used = list(op.ranges) if (world > 1 and not args.allgather) else None
+    ranges_used = list(op.ranges) if (sharded and not args.allgather) else None
     # GCN epoch on the same graph, every rank takes part
     epoch = None
     printed = threading.Lock()
@@ -389,14 +396,14 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         a.plan.set_timing(False)
-        if world == 1:
+        if not sharded:
             del c
         else:
             del op
         torch.cuda.empty_cache()
         try:
             shares = args.chunks
-            if world > 1 and not args.allgather:
+            if sharded and not args.allgather:
                 shares = tuple(hi - lo for lo, hi in ranges_used)
             epoch = rmat_epoch_ms(shard, b_local, world, chunks=shares)
         except Exception as exc:            # the product's line above stays valid whatever happens here
@@ -411,7 +418,7 @@ def main():
             line['gcn_epoch_rmat'] = epoch
         failed = failed or any('error' in leg for leg in line.get('gcn_epoch', []))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if failed:
