@@ -427,17 +427,31 @@ __global__ void rmat_rows_keys_kernel(int scale, int64_t n_pairs, uint64_t key, 
                                       uint32_t ta, uint32_t tb, uint32_t tc, uint64_t row_begin, uint64_t row_end,
                                       unsigned long long* __restrict__ counter, int64_t capacity,
                                       uint64_t* __restrict__ keys) {
-    GCN_GRID_STRIDE(e, n_pairs) {
-        uint64_t u, v;
-        bool loop;
-        rmat_pair(scale, key, label_key, scramble, ta, tb, tc, e, &u, &v, &loop);
-        if (loop) continue;
-        const bool mine_u = u >= row_begin && u < row_end, mine_v = v >= row_begin && v < row_end;
-        const int n_mine = (mine_u ? 1 : 0) + (mine_v ? 1 : 0);
-        if (n_mine == 0) continue;
-        const unsigned long long slot = atomicAdd(counter, (unsigned long long)n_mine);
+    // every wave runs the same number of rounds, so that all 64 lanes meet at the ballots below: one
+    // atomic per wave and round instead of one per key
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t wave_first = first - (threadIdx.x & 63);
+    for (int64_t base = wave_first; base < n_pairs; base += stride) {
+        const int64_t e = base + (threadIdx.x & 63);
+        uint64_t u = 0, v = 0;
+        bool mine_u = false, mine_v = false;
+        if (e < n_pairs) {
+            bool loop;
+            rmat_pair(scale, key, label_key, scramble, ta, tb, tc, e, &u, &v, &loop);
+            mine_u = !loop && u >= row_begin && u < row_end;
+            mine_v = !loop && v >= row_begin && v < row_end;
+        }
+        const uint64_t bu = __ballot(mine_u), bv = __ballot(mine_v);
+        const int total = __popcll(bu) + __popcll(bv);
+        if (total == 0) continue;                                   // the same in every lane of the wave
+        const int lane = threadIdx.x & 63;
+        unsigned long long wave_slot = 0;
+        if (lane == 0) wave_slot = atomicAdd(counter, (unsigned long long)total);
+        wave_slot = __shfl(wave_slot, 0);
         if (!keys) continue;
-        int64_t at = (int64_t)slot;
+        const uint64_t below = (1ull << lane) - 1ull;
+        int64_t at = (int64_t)wave_slot + __popcll(bu & below) + __popcll(bv & below);
         if (mine_u && at < capacity) keys[at++] = ((u - row_begin) << 32) | v;
         if (mine_v && at < capacity) keys[at] = ((v - row_begin) << 32) | u;
     }
