@@ -150,7 +150,8 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, cl
     features -> hidden -> classes on the bench graph, rows sharded over the ranks, in two forms:
 
     ``reference_order_ms``: the reference's own order of operations -- every layer as A_hat . (X' . W)
-    (gcn/layers.py:198-202) over all rows, with the backward products that order implies.  This is
+    (gcn/layers.py:198-202) over ALL rows (logits of unlabelled nodes included, as models.py:54-69 computes
+    them), with the backward products that order implies.  This is
     the "GCN epoch ms" of the metric.
     ``ms``: the same step, same loss and weights to rounding, restructured: first layer as (A_hat . X') . W0
     and hidden rows formed only where a labelled node reads them."""
@@ -187,7 +188,7 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, cl
         torch.cuda.empty_cache()
         return ms, loss, described
 
-    ref_ms, ref_loss, _ = timed(aggregate_first=False, receptive_field=False)
+    ref_ms, ref_loss, _ = timed(aggregate_first=False, receptive_field=False, labelled_logits_only=False)
     ms, loss, (aggregated, pruned) = timed()
     return {'reference_order_ms': ref_ms, 'reference_order_loss': ref_loss, 'ms': ms, 'loss': loss,
             'layers': [int(x_local.shape[1]), hidden, classes], 'steps': steps,

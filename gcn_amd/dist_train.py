@@ -104,7 +104,7 @@ class ShardedGCN(object):
     backward product of that layer (see _AggregatedFirstLayerFn)."""
 
     def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
-                 seed=0, group=None, chunks=4, aggregate_first=None, receptive_field=True):
+                 seed=0, group=None, chunks=4, aggregate_first=None, receptive_field=True, labelled_logits_only=True):
         self.shard, self.group = shard, group
         # ranges of feature columns an exchange is pipelined over: a count, or a tuple of width shares
         self.chunks = chunks if shard.world > 1 else 1
@@ -114,6 +114,9 @@ class ShardedGCN(object):
         self.aggregate_first = (f_in <= sizes[1]) if aggregate_first is None else bool(aggregate_first)
         # a training step of a two-layer model forms only the hidden rows the labelled nodes read
         self.receptive_field = bool(receptive_field)
+        # a training step computes the last layer's product for labelled rows only (the masked loss reads no
+        # other logit) and its backward product over labelled columns only; False: all rows, as the reference does
+        self.labelled_logits_only = bool(labelled_logits_only)
         dev = shard.local.device
         g = torch.Generator(device=dev)
         g.manual_seed(self.seed)                       # every rank draws the same replicated weights
@@ -284,7 +287,8 @@ class ShardedGCN(object):
                 else:                                                     # a rank without labelled nodes
                     dlogits, local_loss = torch.zeros_like(logits), torch.zeros(1, device=logits.device)
             else:
-                logits = self.forward(x_local, train=True, logit_plans=self._logit_plans(mask_local))
+                logits = self.forward(x_local, train=True,
+                                      logit_plans=self._logit_plans(mask_local) if self.labelled_logits_only else None)
                 stats, dlogits = sparse.softmax_xent(logits.detach(), labels_local, mask_local, mask_mean)
                 local_loss = stats[:, 0].mean().reshape(1)
             grads = torch.autograd.grad(logits, self.weights, grad_outputs=dlogits)

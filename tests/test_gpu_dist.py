@@ -360,6 +360,12 @@ def test_receptive_field_step_equals_the_full_step():
         if receptive:
             rows = model._receptive_plans(mask)['rows']
             assert 0 < rows.numel() < n // 2                      # a fraction of the hidden rows was formed
+    # the reference's own form of the step -- A.(X'.W) in both layers, the logits of every row -- follows the
+    # same loss curve (its first layer is summed in another order: equal to rounding, not to the bit)
+    plain = ShardedGCN(shard, f_in, [hidden], classes, dropout=0.5, seed=9, aggregate_first=False,
+                       receptive_field=False, labelled_logits_only=False)
+    plain_losses = [float(plain.train_step(x, labels, mask)) for _ in range(4)]
+    assert np.allclose(plain_losses, runs[0][0], rtol=1e-4)
     (l0, w0), (l1, w1) = runs
     assert np.allclose(l0, l1, rtol=1e-6) and l0[-1] < l0[0]
     for a, b in zip(w0, w1):        # Adam divides by sqrt(v): entries whose gradient is nearly zero amplify rounding
