@@ -592,9 +592,13 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                 float bv[kUnroll][VPL][VEC];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
-                    const float* brow = b + (uint64_t)cidx[u] * (uint64_t)ldb;
-                    if (HUBS && cidx[u] < hub_rows) {
-                        const float* hrow = hub_lds + cidx[u] * (uint32_t)f;
+                    // a slot past the row's end holds an entry of a later row (batches are read whole): point
+                    // it at this batch's first row of B, which is being fetched anyway, instead of gathering
+                    // a row nobody adds -- the path behind the L2 is what a narrow product runs out of
+                    const uint32_t cu = (u == 0 || u < rem) ? cidx[u] : cidx[0];
+                    const float* brow = b + (uint64_t)cu * (uint64_t)ldb;
+                    if (HUBS && cu < hub_rows) {
+                        const float* hrow = hub_lds + cu * (uint32_t)f;
 #pragma unroll
                         for (int v = 0; v < VPL; ++v) load_vec<VEC>(hrow + lcol[v], bv[u][v]);
                     } else {
