@@ -112,7 +112,7 @@ def test_sparse_dropout_form_on_the_large_matrix(big_hat, oracle, f):
 
 
 def test_scale_22_width_512_properties(oracle):
-    """BASELINE config 4 (R-MAT 2^22 nodes, 512 columns) through properties that need no full CPU
+    """The 2^22-node, 512-column roofline-sweep size (R-MAT, average degree 32) through properties that need no full CPU
     product: exact linearity, sampled rows against the serial loop, operator symmetry, A.1."""
     import torch
     from gcn_amd import sparse
