@@ -5,7 +5,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gcn_amd import sparse   # noqa: E402
+from gcn_amd import _lib, sparse   # noqa: E402
+
+if '--lib' in sys.argv:                      # an experimental build of the library instead of the in-tree one
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index('--lib') + 1])
 
 
 def timed(fn, reps=7, warmup=2):
