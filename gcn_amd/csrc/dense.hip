@@ -1,6 +1,7 @@
 // Dense pieces of the GCN layer: tf.nn.dropout (gcn/layers.py:185) and the feature transform
 // H.W (gcn/layers.py:32-33) on the float32 MFMA pipe of gfx950.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -465,10 +466,271 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same product, same tile and same order of additions, for the part of a problem that needs no guard
+// anywhere: whole 128-row panels, n a multiple of 128, k a multiple of 32, 16-byte aligned rows.
+// What it removes is vector arithmetic outside the MFMAs.  With three blocks on a CU the MFMA pipe of a
+// SIMD is saturated by the other blocks' waves, and every ordinary vector instruction of a wave waits for
+// a gap between their MFMAs -- about one MFMA time (64 cycles) each.  Measured with per-block
+// timestamps on 2^22 x 512 x 512: of the 97 us a tile holds its slot, 12.7 us went to the ~250 vector
+// instructions before the first stage was in LDS and 8.5 us to the 64 stores of a lane at 5 vector
+// instructions each, against 73 us in the k loop.  So here
+//  - the tile comes from the block index by shifts (grid x = XCD + 8 * column tile, grid y = group of 8
+//    row panels: the blocks of an XCD still walk the column tiles of one panel one after the other),
+//  - every global access is a buffer instruction: a per-lane byte offset computed once per tile, and a
+//    wave-uniform offset (k stage, row of the output tile) kept and advanced in scalar registers,
+//  - ReLU is one v_med3_f32 per element.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+enum { kEpiPlain = 0, kEpiGate = 1 };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_range_buffer(const void* base) {
+    // raw buffer (stride 0), no range clamp below 4 GiB, 32-bit data format
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
+}
+
+template <bool TRANS_B, int EPI>
+__global__ __launch_bounds__(kBlock, 3) void gemm_panels_kernel(int tiles_m, int n_ktiles,
+                                                               const float* __restrict__ a, int64_t lda,
+                                                               const float* __restrict__ b, int64_t ldb,
+                                                               float* __restrict__ c, int64_t ldc, int relu,
+                                                               const float* __restrict__ gate, int64_t ldg,
+                                                               float divisor) {
+    constexpr int kBM = 128, BN = 128, kBK = 32, MT = 2, NT = 2;
+    constexpr int kAPitch = kBK + 4, kBPitch = BN + 4;
+    __shared__ __attribute__((aligned(16))) float as[kBM * kAPitch];
+    __shared__ __attribute__((aligned(16))) float bs[TRANS_B ? BN * kAPitch : kBK * kBPitch];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int panel = (int)blockIdx.y * 8 + (int)(blockIdx.x & 7);
+    if (panel >= tiles_m) return;
+    const int64_t m0 = (int64_t)panel * kBM;
+    const int64_t n0 = (int64_t)(blockIdx.x >> 3) * BN;
+
+    const __amdgpu_buffer_rsrc_t res_a = whole_range_buffer(a + m0 * lda);
+    const __amdgpu_buffer_rsrc_t res_b = whole_range_buffer(TRANS_B ? b + n0 * ldb : b + n0);
+    // A: rows tid / 8 + 32 i, k quad tid % 8.  B [k x n]: k row tid / 32 + 8 p, column quad tid % 32.
+    // B [n x k]: column tid / 8 + 32 p, k quad tid % 8.
+    const int a_voff = ((tid >> 3) * (int)lda + (tid & 7) * 4) * 4;
+    const int b_voff = TRANS_B ? ((tid >> 3) * (int)ldb + (tid & 7) * 4) * 4 : ((tid >> 5) * (int)ldb + (tid & 31) * 4) * 4;
+    const int a_step = 32 * (int)lda * 4;                                   // unit i -> i + 1
+    const int b_step = TRANS_B ? 32 * (int)ldb * 4 : 8 * (int)ldb * 4;       // unit p -> p + 1
+    const int b_kstep = TRANS_B ? kBK * 4 : kBK * (int)ldb * 4;              // one k stage
+    float4 ra[4], rb[4];
+    auto load_stage = [&](int a_k, int b_k) {      // scalar byte offsets of the stage in A and in B
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4v v = __builtin_bit_cast(
+                f32x4v, __builtin_amdgcn_raw_buffer_load_b128(res_a, a_voff, a_k + i * a_step, 0));
+            ra[i] = make_float4(v.x, v.y, v.z, v.w);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x4v v = __builtin_bit_cast(
+                f32x4v, __builtin_amdgcn_raw_buffer_load_b128(res_b, b_voff, b_k + p * b_step, 0));
+            rb[p] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
+    float* const as_w = as + (tid >> 3) * kAPitch + (tid & 7) * 4;
+    float* const bs_w = TRANS_B ? bs + (tid >> 3) * kAPitch + (tid & 7) * 4 : bs + (tid >> 5) * kBPitch + (tid & 31) * 4;
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(as_w + 32 * i * kAPitch) = ra[i];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<float4*>(bs_w + (TRANS_B ? 32 * p * kAPitch : 8 * p * kBPitch)) = rb[p];
+    };
+
+    f32x16 acc[MT][NT];
+    const int kh = (lane >> 5) * (kBK / 2);
+    const int l31 = lane & 31;
+    const float* const as_r = as + (wm * MT * 32 + l31) * kAPitch + kh;
+    const float* const bs_r = TRANS_B ? bs + (wn * NT * 32 + l31) * kAPitch + kh : bs + kh * kBPitch + wn * NT * 32 + l31;
+    auto read_frags = [&](int kq, float4 (&av)[MT], float (&bv)[NT][4]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const float4*>(as_r + i * 32 * kAPitch + kq);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            if (TRANS_B) {
+                const float4 t = *reinterpret_cast<const float4*>(bs_r + j * 32 * kAPitch + kq);
+                bv[j][0] = t.x;
+                bv[j][1] = t.y;
+                bv[j][2] = t.z;
+                bv[j][3] = t.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[j][e] = bs_r[(kq + e) * kBPitch + j * 32];
+            }
+    };
+    // `first`: the accumulators start as the zero C operand of their first MFMA (no 64 moves per lane)
+    auto mfma_group = [&](const float4 (&av)[MT], const float (&bv)[NT][4], auto first) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float ax = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (decltype(first)::value && e == 0) {
+                        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                                             0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bv[j][e], zero, 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bv[j][e], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+    };
+    auto compute = [&](auto first) {
+        constexpr int kGroups = kBK / 8;
+        float4 av[2][MT];
+        float bv[2][NT][4];
+        read_frags(0, av[0], bv[0]);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            if (g + 1 < kGroups) read_frags(4 * (g + 1), av[(g + 1) & 1], bv[(g + 1) & 1]);
+            if (g == 0)
+                mfma_group(av[g & 1], bv[g & 1], first);
+            else
+                mfma_group(av[g & 1], bv[g & 1], std::false_type{});
+        }
+    };
+
+    load_stage(0, 0);
+    store_tile();
+    __syncthreads();
+    if (n_ktiles == 1) {
+        compute(std::true_type{});
+    } else {
+        int a_k = kBK * 4, b_k = b_kstep;
+        load_stage(a_k, b_k);
+        compute(std::true_type{});
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        for (int t = 2; t < n_ktiles; ++t) {
+            a_k += kBK * 4;
+            b_k += b_kstep;
+            load_stage(a_k, b_k);
+            compute(std::false_type{});
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
+        compute(std::false_type{});
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const __amdgpu_buffer_rsrc_t res_c = whole_range_buffer(c + m0 * ldc + n0);
+    const int c_voff = (4 * (lane >> 5) * (int)ldc + l31) * 4;
+    if (EPI == kEpiGate) {
+        // C = gate > 0 ? (A.B) / divisor : 0 (the backward of dropout(relu(.)) folded into the product).
+        // For a power-of-two divisor (keep_prob = 0.5) the quotient is the product with the inverse, bit for
+        // bit: one multiplication instead of the dozen instructions of a correctly rounded division.
+        const __amdgpu_buffer_rsrc_t res_g = whole_range_buffer(gate + m0 * ldg + n0);
+        const int g_voff = (4 * (lane >> 5) * (int)ldg + l31) * 4;
+        const bool scale_exact = (__float_as_uint(divisor) & 0x007fffffu) == 0;
+        const float inv_divisor = 1.0f / divisor;
+        auto gated_store = [&](auto exact) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float gv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2);
+                        const unsigned int bits = __builtin_amdgcn_raw_buffer_load_b32(
+                            res_g, g_voff, (row * (int)ldg + (wn * NT + j) * 32) * 4, 0);
+                        gv[e] = __uint_as_float(bits);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2);
+                        const float q = decltype(exact)::value ? acc[i][j][e] * inv_divisor
+                                                               : __fdiv_rn(acc[i][j][e], divisor);
+                        const float v = gv[e] > 0.0f ? q : 0.0f;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), res_c, c_voff,
+                                                              (row * (int)ldc + (wn * NT + j) * 32) * 4, 0);
+                    }
+                }
+        };
+        if (scale_exact)
+            gated_store(std::true_type{});
+        else
+            gated_store(std::false_type{});
+        return;
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2);
+                    float v;   // one instruction: the compiler's fmaxf is a canonicalising max followed by the max
+                    asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(acc[i][j][e]));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), res_c, c_voff,
+                                                          (row * (int)ldc + (wn * NT + j) * 32) * 4, 0);
+                }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2);
+                const float v = acc[i][j][e];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), res_c, c_voff,
+                                                      (row * (int)ldc + (wn * NT + j) * 32) * 4, 0);
+            }
+}
+
+// true when gemm_panels_kernel can take the leading whole panels of this problem
+static bool panels_form_fits(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                             int trans_b, int64_t ldc, const float* gate, int64_t ldg) {
+    const int64_t limit = (int64_t)1 << 29;          // every byte offset inside a tile's buffers stays below 2^31
+    if (m < 128 || n % 128 != 0 || k % 32 != 0 || k < 32) return false;
+    if (lda % 4 || ldb % 4 || ((uintptr_t)a & 15) || ((uintptr_t)b & 15)) return false;
+    if (128 * lda + k >= limit || 128 * ldc + n >= limit || (gate && 128 * ldg + n >= limit)) return false;
+    if (trans_b ? 128 * ldb + k >= limit : (k + 32) * ldb + 128 >= limit) return false;
+    return m / 128 <= 8 * 65535;
+}
+
 template <int kBM, int BN>
 static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
                        int trans_b, float* c, int64_t ldc, int relu, hipStream_t st, const float* gate = nullptr,
                        int64_t ldg = 0, float divisor = 1.0f, const OutDrop* out_drop = nullptr) {
+    if (kBM == 128 && BN == 128 && !out_drop && panels_form_fits(m, n, k, a, lda, b, ldb, trans_b, ldc, gate, ldg)) {
+        // whole 128-row panels through the kernel without guards, the rows left over through the general one
+        const int64_t panels = m / 128;
+        const dim3 grid((unsigned)(8 * (n / 128)), (unsigned)ceil_div(panels, 8));
+#define GCN_PANELS_GO(TB, EPI)                                                                                \
+    gemm_panels_kernel<TB, EPI><<<grid, kBlock, 0, st>>>((int)panels, (int)(k / 32), a, lda, b, ldb, c, ldc, relu, gate, \
+                                                         ldg, divisor)
+        if (gate) {
+            if (trans_b)
+                GCN_PANELS_GO(true, kEpiGate);
+            else
+                GCN_PANELS_GO(false, kEpiGate);
+        } else {
+            if (trans_b)
+                GCN_PANELS_GO(true, kEpiPlain);
+            else
+                GCN_PANELS_GO(false, kEpiPlain);
+        }
+#undef GCN_PANELS_GO
+        GCN_LAUNCH_CHECK();
+        const int64_t done = panels * 128;
+        if (done == m) return GCN_OK;
+        return launch_gemm<kBM, BN>(m - done, n, k, a + done * lda, lda, b, ldb, trans_b, c + done * ldc, ldc, relu, st,
+                                    gate ? gate + done * ldg : nullptr, ldg, divisor, nullptr);
+    }
     const OutDrop od = out_drop ? *out_drop : OutDrop{0, 1.0f, 0, 0, nullptr, 0, 0};
     const int64_t tiles_m = ceil_div(m, kBM), tiles_n = ceil_div(n, BN);
     const int64_t n_tiles = tiles_m * tiles_n;

@@ -50,6 +50,49 @@ def test_gemm_mfma_against_float64(oracle, m, n, k, trans_b):
     assert np.array_equal(out_relu, np.maximum(out, 0))
 
 
+@pytest.mark.parametrize('m,n,k', [(128, 128, 32), (5000, 256, 64), (1000, 384, 96), (257, 128, 512), (1280, 512, 256)])
+@pytest.mark.parametrize('trans_b', [False, True])
+def test_whole_panel_form_gives_the_bits_of_the_guarded_form(oracle, m, n, k, trans_b):
+    """Whole 128-row panels with n a multiple of 128 and k of 32 go through the kernel without guards
+    (buffer addressing, scalar offsets), the rows left over and every other shape through the guarded one.
+    Both add the products of an element in the same order: the same problem posed so that it takes the
+    guarded kernel (four more columns) must give the same bits, with ReLU, with the gate of the ReLU /
+    dropout backward, and on strided operands."""
+    import torch
+    from gcn_amd import sparse
+    a = _t(oracle.synthetic_dense(m, k, seed=51))
+    b_wide = oracle.synthetic_dense(k, n + 4, seed=52)
+    if trans_b:
+        bw = _t(np.ascontiguousarray(b_wide.T))            # (n + 4) x k
+        b_part = bw[:n]
+    else:
+        bw = _t(b_wide)                                     # k x (n + 4)
+        b_part = bw[:, :n]                                  # row pitch n + 4
+    guarded = sparse.gemm(a, bw, trans_b=trans_b)[:, :n]
+    panels = sparse.gemm(a, b_part, trans_b=trans_b)
+    assert torch.equal(panels, guarded)
+    ref = a.double() @ _t(b_wide[:, :n]).double()
+    assert float((panels.double() - ref).abs().max()) <= REL_TOL * float(ref.abs().max())
+    assert torch.equal(sparse.gemm(a, b_part, trans_b=trans_b, relu=True), torch.clamp(guarded, min=0))
+    gate = _t(oracle.synthetic_dense(m, n, seed=53))
+    gate = torch.where(gate > 0.3, gate, torch.zeros_like(gate))
+    for keep in (0.5, 0.8, 0.25):                            # a power of two divides as a product with the inverse
+        got = sparse.gemm_gated(a, b_part, gate, keep, trans_b=trans_b)
+        want = torch.where(gate > 0, guarded / torch.full_like(guarded, keep), torch.zeros_like(guarded))
+        assert torch.equal(got, want)
+    # strided A, strided C and a strided gate
+    a_wide = torch.zeros((m, k + 8), device='cuda')
+    a_wide[:, 4:4 + k] = a
+    c_wide = torch.full((m, n + 8), -3.0, device='cuda')
+    sparse.gemm(a_wide[:, 4:4 + k], b_part, trans_b=trans_b, out=c_wide[:, 3:3 + n])
+    assert torch.equal(c_wide[:, 3:3 + n], guarded)
+    assert bool((c_wide[:, :3] == -3.0).all()) and bool((c_wide[:, 3 + n:] == -3.0).all())
+    g_wide = torch.zeros((m, n + 4), device='cuda')
+    g_wide[:, 1:1 + n] = gate
+    sparse.gemm_gated(a_wide[:, 4:4 + k], b_part, g_wide[:, 1:1 + n], 0.5, trans_b=trans_b, out=c_wide[:, 3:3 + n])
+    assert torch.equal(c_wide[:, 3:3 + n], torch.where(gate > 0, guarded * 2, torch.zeros_like(guarded)))
+
+
 def test_gemm_identity_with_asymmetric_operand():
     """A = I against an asymmetric B catches a swapped row/column map of the MFMA result."""
     import torch
