@@ -37,3 +37,15 @@ for m, k, n in ((1 << 22, 512, 512), (1 << 24, 256, 256), (8192, 8192, 8192)):
         m, k, n, ours, flop / ours / 1e9, lib, flop / lib / 1e9), flush=True)
     del a, b, c
     torch.cuda.empty_cache()
+
+# the weight gradient: C[k x n] = A^T . G, reduction over the m rows
+for m, k, n in ((1 << 24, 256, 256), (1 << 22, 512, 512), (1 << 21, 256, 256)):
+    a = sparse.synthetic_dense(m, k, seed=3)
+    g = sparse.synthetic_dense(m, n, seed=5)
+    ours = timed(lambda: sparse.gemm_tn(a, g))
+    lib = timed(lambda: torch.matmul(a.t(), g)) if '--no-lib' not in sys.argv else float('nan')
+    flop = 2.0 * m * n * k
+    print('A^T.G %d rows, %d x %d: ours %.3f ms = %.1f TF/s   torch.matmul %.3f ms = %.1f TF/s' % (
+        m, k, n, ours, flop / ours / 1e9, lib, flop / lib / 1e9), flush=True)
+    del a, g
+    torch.cuda.empty_cache()
