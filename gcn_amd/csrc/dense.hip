@@ -769,7 +769,7 @@ template <int TM, int BN>
 __global__ __launch_bounds__(64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)), 3)
 void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a, int64_t lda,
                     const float* __restrict__ g, int64_t ldg, float* __restrict__ out, int64_t ldo,
-                    int64_t split_stride, int64_t rows_per_split, int vec_ok, int64_t tiles_n) {
+                    int64_t split_stride, int64_t rows_per_split, int vec_ok, int tiles_n, int tiles, int splits) {
     constexpr int kTiles = (TM / 32) * (BN / 32);
     constexpr int kWaves = kTiles > 4 ? 4 : kTiles;
     constexpr int kThreads = 64 * kWaves;
@@ -783,9 +783,16 @@ void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a
     __shared__ __attribute__((aligned(16))) float gs[kRows * kGPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / kWavesN, wn = wave % kWavesN;
-    const int64_t k0 = (blockIdx.x / tiles_n) * TM;  // first column of A = first row of C
-    const int64_t n0 = (blockIdx.x % tiles_n) * BN;
-    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_split;
+    // Block numbering: the tiles of one row range read the same rows of A and G, so they run on one XCD
+    // (block ids equal modulo 8), one after the other in dispatch order, and share its L2: XCD x takes
+    // the row ranges x, x + 8, ...
+    const unsigned per_xcd = blockIdx.x >> 3;
+    const int tile = (int)(per_xcd % (unsigned)tiles);
+    const int split = (int)(per_xcd / (unsigned)tiles) * 8 + (int)(blockIdx.x & 7);
+    if (split >= splits) return;
+    const int64_t k0 = (int64_t)(tile / tiles_n) * TM;  // first column of A = first row of C
+    const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
+    const int64_t r_begin = (int64_t)split * rows_per_split;
     const int64_t r_end = (r_begin + rows_per_split < m) ? r_begin + rows_per_split : m;
 
     f32x16 acc[MT][NT];
@@ -888,7 +895,7 @@ void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a
         if (t + 1 < n_stages) store_tile();
         __syncthreads();
     }
-    float* dst = out + (int64_t)blockIdx.y * split_stride;
+    float* dst = out + (int64_t)split * split_stride;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1076,10 +1083,13 @@ int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda
         split_stride = k * n;
     }
     const int vec_ok = (lda % 4 == 0) && (ldg % 4 == 0) && (((uintptr_t)a & 15) == 0) && (((uintptr_t)g & 15) == 0);
-    const dim3 grid((unsigned)s.tiles, (unsigned)s.splits);
+    const int64_t n_blocks = s.tiles * align_up(s.splits, 8);
+    if (n_blocks > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
+    const dim3 grid((unsigned)n_blocks);
 #define GCN_TN_GO(TM, BN)                                                                                          \
     gemm_tn_kernel<TM, BN><<<grid, 64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)), 0, st>>>(           \
-        m, n, k, a, lda, g, ldg, out, ldo, split_stride, s.rows_per_split, vec_ok, s.tiles_n)
+        m, n, k, a, lda, g, ldg, out, ldo, split_stride, s.rows_per_split, vec_ok, (int)s.tiles_n, (int)s.tiles,    \
+        (int)s.splits)
     if (s.tm == 128 && s.bn == 128)
         GCN_TN_GO(128, 128);
     else if (s.tm == 128)
