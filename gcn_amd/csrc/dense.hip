@@ -765,7 +765,10 @@ static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
 // ranges, one block per (tile, range); with more than one range the partial tiles go to the workspace
 // and reduce_splits_kernel adds them in range order, so the result does not depend on scheduling.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int BN>
+// BUF (128 x 128 tiles only): the unguarded stages are read with buffer instructions -- per-lane byte
+// offsets computed once, the stage offset in a scalar register -- so that the loop holds no vector
+// arithmetic and 16 registers fewer (see gemm_panels_kernel).
+template <int TM, int BN, bool BUF>
 __global__ __launch_bounds__(64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)), 3)
 void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a, int64_t lda,
                     const float* __restrict__ g, int64_t ldg, float* __restrict__ out, int64_t ldo,
@@ -881,12 +884,42 @@ void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a
     }
     __syncthreads();
     int64_t t = 0;
-    for (; t + 1 < n_full; ++t) {
-        load_fast(r_begin + (t + 1) * kRows);
-        compute();
-        __syncthreads();
-        store_tile();
-        __syncthreads();
+    if (BUF) {
+        const __amdgpu_buffer_rsrc_t res_x = whole_range_buffer(a + r_begin * lda + k0);
+        const __amdgpu_buffer_rsrc_t res_g = whole_range_buffer(g + r_begin * ldg + n0);
+        // unit p of a thread: row tid / 32 + 8 p of the stage, column quad tid % 32
+        const int x_voff = ((tid >> 5) * (int)lda + (tid & 31) * 4) * 4;
+        const int g_voff = ((tid >> 5) * (int)ldg + (tid & 31) * 4) * 4;
+        const int x_unit = 8 * (int)lda * 4, g_unit = 8 * (int)ldg * 4;
+        int x_stage = 0, g_stage = 0;
+        for (; t + 1 < n_full; ++t) {
+            x_stage += kRows * (int)lda * 4;
+            g_stage += kRows * (int)ldg * 4;
+#pragma unroll
+            for (int p = 0; p < kXPer; ++p) {
+                const f32x4v v = __builtin_bit_cast(
+                    f32x4v, __builtin_amdgcn_raw_buffer_load_b128(res_x, x_voff, x_stage + p * x_unit, 0));
+                rx[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
+#pragma unroll
+            for (int p = 0; p < kGPer; ++p) {
+                const f32x4v v = __builtin_bit_cast(
+                    f32x4v, __builtin_amdgcn_raw_buffer_load_b128(res_g, g_voff, g_stage + p * g_unit, 0));
+                rg[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
+            compute();
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
+    } else {
+        for (; t + 1 < n_full; ++t) {
+            load_fast(r_begin + (t + 1) * kRows);
+            compute();
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
     }
     for (; t < n_stages; ++t) {
         if (t + 1 < n_stages) load_guarded(r_begin + (t + 1) * kRows);
@@ -1086,18 +1119,22 @@ int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda
     const int64_t n_blocks = s.tiles * align_up(s.splits, 8);
     if (n_blocks > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
     const dim3 grid((unsigned)n_blocks);
-#define GCN_TN_GO(TM, BN)                                                                                          \
-    gemm_tn_kernel<TM, BN><<<grid, 64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)), 0, st>>>(           \
+#define GCN_TN_GO(TM, BN, BUF)                                                                                     \
+    gemm_tn_kernel<TM, BN, BUF><<<grid, 64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)), 0, st>>>(      \
         m, n, k, a, lda, g, ldg, out, ldo, split_stride, s.rows_per_split, vec_ok, (int)s.tiles_n, (int)s.tiles,    \
         (int)s.splits)
-    if (s.tm == 128 && s.bn == 128)
-        GCN_TN_GO(128, 128);
+    // byte offsets inside one row range of a block stay below 2^31
+    const bool buf_ok = vec_ok && (s.rows_per_split + 32) * std::max(lda, ldg) < ((int64_t)1 << 29);
+    if (s.tm == 128 && s.bn == 128 && buf_ok)
+        GCN_TN_GO(128, 128, true);
+    else if (s.tm == 128 && s.bn == 128)
+        GCN_TN_GO(128, 128, false);
     else if (s.tm == 128)
-        GCN_TN_GO(128, 32);
+        GCN_TN_GO(128, 32, false);
     else if (s.bn == 128)
-        GCN_TN_GO(32, 128);
+        GCN_TN_GO(32, 128, false);
     else
-        GCN_TN_GO(32, 32);
+        GCN_TN_GO(32, 32, false);
 #undef GCN_TN_GO
     GCN_LAUNCH_CHECK();
     if (s.splits > 1) {

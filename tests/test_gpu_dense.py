@@ -128,7 +128,7 @@ def test_gemm_strided_and_unaligned_operands(oracle, trans_b):
 
 
 @pytest.mark.parametrize('m,n,k', [(2708, 7, 16), (2708, 16, 1433), (19717, 3, 16), (100000, 256, 256), (1000, 130, 33),
-                                   (31, 5, 9), (1, 1, 1), (300000, 16, 200), (65, 128, 32)])
+                                   (31, 5, 9), (1, 1, 1), (300000, 16, 200), (65, 128, 32), (70001, 384, 512)])
 def test_weight_gradient_product_against_float64(oracle, m, n, k):
     """dW = H^T . dP (the reduction over the nodes), including shapes that split the rows over many
     blocks, ragged edges in every dimension and operands that are slices of wider matrices."""
@@ -147,6 +147,9 @@ def test_weight_gradient_product_against_float64(oracle, m, n, k):
     sparse.gemm_tn(a_wide[:, 1:1 + k], _t(g), out=c_wide[:, 2:2 + n])
     got = c_wide.cpu().numpy()
     assert np.abs(got[:, 2:2 + n] - ref).max() <= tol
+    # the unaligned operand takes the guarded loader, the aligned one (128 x 128 tiles) buffer loads with
+    # scalar offsets: same row ranges, same order of additions, same bits
+    assert torch.equal(c_wide[:, 2:2 + n], out)
     assert np.all(got[:, :2] == 3.0) and np.all(got[:, 2 + n:] == 3.0)
 
 
