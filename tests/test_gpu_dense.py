@@ -93,6 +93,41 @@ def test_whole_panel_form_gives_the_bits_of_the_guarded_form(oracle, m, n, k, tr
     assert torch.equal(c_wide[:, 3:3 + n], torch.where(gate > 0, guarded * 2, torch.zeros_like(guarded)))
 
 
+@pytest.mark.parametrize('pitch', [(1 << 22) - 64, (1 << 22) + 64])
+def test_whole_panel_form_at_the_largest_row_pitch_it_takes(oracle, pitch):
+    """The kernel without guards addresses a tile with 32-bit byte offsets: it takes operands whose 128 rows
+    span less than 2^31 bytes (row pitch below 2^22 floats) and leaves wider ones to the guarded kernel.
+    Just below the limit the offsets are the largest it ever forms; just above, the other kernel runs:
+    the same bits as the contiguous problem either way, for A, for C and for the gate."""
+    import torch
+    from gcn_amd import sparse
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2 ** 30:
+        pytest.skip('needs 24 GiB of free HBM')
+    m, n, k = 256, 128, 64
+    a = _t(oracle.synthetic_dense(m, k, seed=54))
+    b = _t(oracle.synthetic_dense(k, n, seed=55))
+    want = sparse.gemm(a, b)
+    big = torch.zeros((m, pitch), device='cuda')
+    big[:, 8:8 + k] = a
+    assert torch.equal(sparse.gemm(big[:, 8:8 + k], b), want)                  # pitch of A
+    big.zero_()
+    sparse.gemm(a, b, out=big[:, 4:4 + n])                                      # pitch of C
+    assert torch.equal(big[:, 4:4 + n], want) and float(big[:, 4 + n:4 + n + 64].abs().max()) == 0.0
+    gate = torch.where(want > 0.1, want, torch.zeros_like(want))
+    gated = sparse.gemm_gated(a, b, gate, 0.5)
+    gbig = torch.zeros((m, pitch), device='cuda')
+    gbig[:, :n] = gate
+    assert torch.equal(sparse.gemm_gated(a, b, gbig[:, :n], 0.5), gated)        # pitch of the gate
+    # the transposed operand B [n x k] with that pitch
+    del gbig
+    big.zero_()
+    big[:n, :k] = b.t()
+    assert torch.equal(sparse.gemm(a, big[:n, :k], trans_b=True), want)
+    del big
+    torch.cuda.empty_cache()
+
+
 def test_gemm_identity_with_asymmetric_operand():
     """A = I against an asymmetric B catches a swapped row/column map of the MFMA result."""
     import torch
