@@ -479,7 +479,10 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
 //    row panels: the blocks of an XCD still walk the column tiles of one panel one after the other),
 //  - every global access is a buffer instruction: a per-lane byte offset computed once per tile, and a
 //    wave-uniform offset (k stage, row of the output tile) kept and advanced in scalar registers,
-//  - ReLU is one v_med3_f32 per element.
+//  - ReLU is one v_max_f32 against the constant 0 per element.  It writes the bits of the guarded kernel's
+//    `v > 0 ? v : 0` for everything an accumulator can hold: the hardware maximum returns +0 for -0 and
+//    the other operand (+0) for a quiet NaN -- the only kind arithmetic produces --, and an infinity
+//    passes as itself (tested on rows that hold NaN, both infinities and negative underflow).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 enum { kEpiPlain = 0, kEpiGate = 1 };

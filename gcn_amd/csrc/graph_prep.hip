@@ -1,7 +1,9 @@
 // Graph preprocessing for the GCN propagation path: COO -> CSR with self-loops, row sums,
 // D^-1/2 scaling, stable transpose, R-MAT generation.  Integer kernels; the float64 scaling
 // follows gcn/utils.py:297-323 operation by operation.
+#include <atomic>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -356,17 +358,6 @@ __global__ void relabel_keys_kernel(int64_t n_rows, int64_t nnz, const int64_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// index range check
-// ------------------------------------------------------------------------------------------------
-__global__ void check_indices_kernel(int64_t nnz, const int32_t* __restrict__ indices, int64_t n_cols,
-                                     int* __restrict__ bad) {
-    GCN_GRID_STRIDE(k, nnz) {
-        const int64_t c = indices[k];
-        if (c < 0 || c >= n_cols) atomicOr(bad, 1);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // R-MAT and synthetic features
 // ------------------------------------------------------------------------------------------------
 __global__ void rmat_keys_kernel(int scale, int64_t n_pairs, int64_t n_loops, uint64_t key, uint64_t label_key,
@@ -461,43 +452,94 @@ __global__ void diagonal_keys_kernel(int64_t n_local, uint64_t row_begin, uint64
     GCN_GRID_STRIDE(i, n_local) keys[i] = ((uint64_t)i << 32) | (row_begin + (uint64_t)i);
 }
 
-// bit 0: a row index outside [0, n_rows); bit 1: a column index outside [0, n_cols)
-__global__ void check_coo_kernel(int64_t nnz, const int32_t* __restrict__ rows, int64_t n_rows,
-                                 const int32_t* __restrict__ cols, int64_t n_cols, int* __restrict__ bad) {
+// One range check: the n values at p must lie in [0, bound).  A null p checks nothing.
+struct RangeCheck {
+    const int32_t* p;
+    int64_t n;
+    int64_t bound;
+};
+
+// Up to three checks in one pass; bit i of *bad is set when check i found a value outside its range.
+__global__ void check_ranges_kernel(RangeCheck c0, RangeCheck c1, RangeCheck c2, int64_t n_max,
+                                    int* __restrict__ bad) {
     int mine = 0;
-    GCN_GRID_STRIDE(k, nnz) {
-        if (rows) {
-            const int64_t r = rows[k];
-            if (r < 0 || r >= n_rows) mine |= 1;
+    GCN_GRID_STRIDE(k, n_max) {
+        if (c0.p && k < c0.n) {
+            const int64_t v = c0.p[k];
+            if (v < 0 || v >= c0.bound) mine |= 1;
         }
-        if (cols) {
-            const int64_t c = cols[k];
-            if (c < 0 || c >= n_cols) mine |= 2;
+        if (c1.p && k < c1.n) {
+            const int64_t v = c1.p[k];
+            if (v < 0 || v >= c1.bound) mine |= 2;
+        }
+        if (c2.p && k < c2.n) {
+            const int64_t v = c2.p[k];
+            if (v < 0 || v >= c2.bound) mine |= 4;
         }
     }
     if (mine) atomicOr(bad, mine);
 }
 
-// Range check of a COO index pair before any kernel uses an index as an address: the reference raises
-// ValueError (scipy's coo_matrix) or InvalidArgumentError (TensorFlow's per-nonzero check) for the same
-// inputs.  Waits for the stream.
+// Flag words of the range checks: a small array inside the library (one copy per GPU), so that a check
+// makes no hipMalloc / hipFree -- a hipFree waits for the whole device.  A call takes the next of
+// kFlagSlots words in turn; a check holds its word only until it returns (it waits for its stream), so
+// the words of up to kFlagSlots host threads checking at once never collide.
+constexpr int kFlagSlots = 256;
+constexpr int kFlagStride = 16;   // ints: one 64-byte line per slot
+constexpr int kMaxDevices = 64;
+static __device__ int range_flags[kFlagSlots * kFlagStride];
+static int* g_flags_ptr[kMaxDevices];
+static std::mutex g_flags_mutex;
+static std::atomic<unsigned> g_flag_turn{0};
+
+static int next_flag_word(int** out) {
+    int dev = -1;
+    GCN_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(GCN_ERR_BAD_ARG, "device ordinal %d is not supported", dev);
+    {
+        std::lock_guard<std::mutex> lock(g_flags_mutex);
+        if (!g_flags_ptr[dev]) {
+            void* p = nullptr;
+            GCN_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(range_flags)));
+            if (!p) return fail(GCN_ERR_HIP, "hipGetSymbolAddress returned a null address for the flag array");
+            g_flags_ptr[dev] = (int*)p;
+        }
+    }
+    *out = g_flags_ptr[dev] + (size_t)(g_flag_turn.fetch_add(1) % kFlagSlots) * kFlagStride;
+    return GCN_OK;
+}
+
+// Range checks before any kernel uses an index as an address: the reference raises ValueError (scipy's
+// coo_matrix) or InvalidArgumentError (TensorFlow's per-nonzero check) for the same inputs.  One kernel
+// for all the checks of a call, no allocation; waits for the stream.  *bits_out: bit i = check i failed.
+static int check_ranges(const RangeCheck (&c)[3], hipStream_t st, int* bits_out) {
+    *bits_out = 0;
+    int64_t n_max = 0;
+    for (const RangeCheck& r : c)
+        if (r.p && r.n > n_max) n_max = r.n;
+    if (n_max == 0) return GCN_OK;
+    int* flag = nullptr;
+    const int rc = next_flag_word(&flag);
+    if (rc != GCN_OK) return rc;
+    GCN_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
+    check_ranges_kernel<<<grid_for(n_max), kBlock, 0, st>>>(c[0], c[1], c[2], n_max, flag);
+    GCN_LAUNCH_CHECK();
+    int host = 0;
+    GCN_HIP_TRY(hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    GCN_HIP_TRY(hipStreamSynchronize(st));
+    *bits_out = host;
+    return GCN_OK;
+}
+
+// rows against n_rows and cols against n_cols (either may be null), nnz of each
 static int check_coo_range(int64_t nnz, const int32_t* rows, int64_t n_rows, const int32_t* cols, int64_t n_cols,
                            hipStream_t st) {
-    if (nnz == 0) return GCN_OK;
-    int* flag = nullptr;
-    GCN_HIP_TRY(hipMalloc(&flag, sizeof(int)));
-    int host = 0;
-    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
-    if (e == hipSuccess) {
-        check_coo_kernel<<<grid_for(nnz), kBlock, 0, st>>>(nnz, rows, n_rows, cols, n_cols, flag);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(flag);
-    if (e != hipSuccess) return fail(GCN_ERR_HIP, "index check failed: %s", hipGetErrorString(e));
-    if (host & 1) return fail(GCN_ERR_INDEX_RANGE, "a row index is outside [0, %lld)", (long long)n_rows);
-    if (host & 2) return fail(GCN_ERR_INDEX_RANGE, "a column index is outside [0, %lld)", (long long)n_cols);
+    const RangeCheck c[3] = {{rows, nnz, n_rows}, {cols, nnz, n_cols}, {nullptr, 0, 0}};
+    int bits = 0;
+    const int rc = check_ranges(c, st, &bits);
+    if (rc != GCN_OK) return rc;
+    if (bits & 1) return fail(GCN_ERR_INDEX_RANGE, "a row index is outside [0, %lld)", (long long)n_rows);
+    if (bits & 2) return fail(GCN_ERR_INDEX_RANGE, "a column index is outside [0, %lld)", (long long)n_cols);
     return GCN_OK;
 }
 
@@ -700,17 +742,16 @@ int gcn_csr_relabel(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* 
     SortScratch s;
     int rc = carve_scratch(workspace, workspace_bytes, nnz, valued, &s);
     if (rc != GCN_OK) return rc;
-    // the new labels become row numbers and column indices: they must lie inside the shape
-    if (new_row) {
-        rc = check_coo_range(n_rows, new_row, n_rows, nullptr, 0, st);
+    // the new labels become row numbers and column indices, the old column indices address new_col:
+    // all three must lie inside the shape (one pass checks them)
+    {
+        const RangeCheck c[3] = {{new_row, n_rows, n_rows}, {new_col, n_cols, n_cols}, {indices, nnz, n_cols}};
+        int bits = 0;
+        rc = check_ranges(c, st, &bits);
         if (rc != GCN_OK) return rc;
+        if (bits & 1) return fail(GCN_ERR_INDEX_RANGE, "a row index is outside [0, %lld)", (long long)n_rows);
+        if (bits & 6) return fail(GCN_ERR_INDEX_RANGE, "a column index is outside [0, %lld)", (long long)n_cols);
     }
-    if (new_col) {
-        rc = check_coo_range(n_cols, nullptr, 0, new_col, n_cols, st);
-        if (rc != GCN_OK) return rc;
-    }
-    rc = check_coo_range(nnz, nullptr, 0, indices, n_cols, st);
-    if (rc != GCN_OK) return rc;
     if (nnz > 0) {
         relabel_keys_kernel<<<grid_for(nnz), kBlock, 0, st>>>(n_rows, nnz, indptr, indices, new_row, new_col, vals,
                                                              s.keys_a, valued ? s.vals_a : nullptr);
@@ -723,22 +764,7 @@ int gcn_csr_relabel(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* 
 
 int gcn_check_indices(int64_t nnz, const int32_t* indices, int64_t n_cols, void* stream) {
     if (nnz < 0 || (nnz > 0 && !indices)) return fail(GCN_ERR_BAD_ARG, "bad argument");
-    if (nnz == 0) return GCN_OK;
-    hipStream_t st = (hipStream_t)stream;
-    int* flag = nullptr;
-    GCN_HIP_TRY(hipMalloc(&flag, sizeof(int)));
-    int host = 0;
-    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
-    if (e == hipSuccess) {
-        check_indices_kernel<<<grid_for(nnz), kBlock, 0, st>>>(nnz, indices, n_cols, flag);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(flag);
-    if (e != hipSuccess) return fail(GCN_ERR_HIP, "index check failed: %s", hipGetErrorString(e));
-    if (host) return fail(GCN_ERR_INDEX_RANGE, "a column index is outside [0, %lld)", (long long)n_cols);
-    return GCN_OK;
+    return check_coo_range(nnz, nullptr, 0, indices, n_cols, (hipStream_t)stream);
 }
 
 int gcn_rmat_csr_bound(int scale, int edge_factor, int flags, int64_t* nnz_capacity, size_t* workspace_bytes) {
