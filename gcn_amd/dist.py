@@ -199,6 +199,7 @@ class HaloPlan(object):
         if not self._collective and operand_rows is None:
             # one process, no communicator: the operand holds every column's row, B is its own halo
             self.compact, self.n_needed, self._identity, self._buffers = local, shard.n_cols, True, {}
+            self._side = None
             self.recv_splits = self.send_splits = [shard.n_cols]
             return
         cols = local.indices.to(torch.int64)
@@ -232,50 +233,94 @@ class HaloPlan(object):
         self.n_needed = int(needed.numel())
         self._identity = False
         self._buffers = {}
+        self._side = None                                            # stream of exchange_ranges, made on first use
 
     def drop_buffers(self, keep_widths=()):
         """Free the cached send / receive buffers of every width not in ``keep_widths``."""
         for key in [k for k in self._buffers if k[0] not in keep_widths]:
             del self._buffers[key]
 
-    def exchange(self, b_local, slot=0, async_op=False):
-        """Rows of the global matrix this rank's shard references, [n_needed x f], in column order.
-
-        ``slot`` picks one of the cached buffer pairs of this width, so that a caller can have one
-        exchange in flight while the product reads the previous one.  With ``async_op`` the pair
-        ``(rows, work)`` is returned and ``work.wait()`` orders the current stream after the
-        exchange; RCCL runs it on its own stream, which is what lets it overlap a product enqueued
-        after the call."""
-        if self._identity:                      # one rank and every column referenced: B itself
-            return (b_local, _Done) if async_op else b_local
-        f = b_local.shape[1]
+    def _buffers_for(self, f, slot, device):
         bufs = self._buffers.get((f, slot))
         if bufs is None:
-            dev = b_local.device
-            bufs = (torch.empty((self.send_rows.numel(), f), dtype=torch.float32, device=dev),
-                    torch.empty((self.n_needed, f), dtype=torch.float32, device=dev))
+            bufs = (torch.empty((self.send_rows.numel(), f), dtype=torch.float32, device=device),
+                    torch.empty((self.n_needed, f), dtype=torch.float32, device=device))
             self._buffers[(f, slot)] = bufs
-        send_buf, b_halo = bufs
+        return bufs
+
+    def exchange_ranges(self, b_local, ranges):
+        """The exchange of every column range of ``ranges``, all issued now: ``[(rows, handle), ...]`` in
+        range order, ``handle.wait()`` ordering the current stream after that range's arrival.
+
+        On the GPU nothing of this runs on the caller's stream.  The send buffers are packed on a side
+        stream of the plan's own -- which first waits for what the caller has enqueued so far, the
+        producer of ``b_local`` and the last readers of the buffers among it -- and every range's
+        collective is handed to RCCL from that stream, so RCCL's stream waits for the packing of its own
+        range and for nothing else.  Range i + 1 is therefore packed while range i is on the links, all
+        the ranges follow each other on the links without a gap, and the caller's products meet neither the
+        packing nor a collective that had to wait for an earlier product.  Every range has buffers of its
+        own (together: one full-width pair)."""
+        if self._identity:
+            return [(b_local[:, lo:hi], _Done) for lo, hi in ranges]
+        staged = self._collective and _through_host(b_local, self.group)
+        if not b_local.is_cuda or staged:
+            # host tensors, and the gloo rehearsal that stages device tensors through the host: in order
+            return [(self.exchange(b_local[:, lo:hi], slot=i), _Done) for i, (lo, hi) in enumerate(ranges)]
+        dev = b_local.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        entry = torch.cuda.Event()
+        entry.record(torch.cuda.current_stream(dev))
+        self._side.wait_event(entry)
+        out = []
+        with torch.cuda.stream(self._side):
+            for i, (lo, hi) in enumerate(ranges):
+                send_buf, b_halo = self._buffers_for(hi - lo, i, dev)
+                sparse.gather_rows(b_local[:, lo:hi], self.send_rows, send_buf)
+                if self._collective:
+                    work = dist.all_to_all_single(b_halo, send_buf, self.recv_splits, self.send_splits,
+                                                  group=self.group, async_op=True)
+                else:                                   # one process standing in for a rank: a device copy
+                    b_halo.copy_(send_buf)
+                    done = torch.cuda.Event()
+                    done.record(self._side)
+                    work = _AfterEvent(done)
+                out.append((b_halo, work))
+        return out
+
+    def exchange(self, b_local, slot=0):
+        """Rows of the global matrix this rank's shard references, [n_needed x f], in column order, moved
+        on the caller's stream (the exchange a product of one column range waits for as a whole).
+        ``slot`` picks one of the cached buffer pairs of this width."""
+        if self._identity:                      # one rank and every column referenced: B itself
+            return b_local
+        send_buf, b_halo = self._buffers_for(b_local.shape[1], slot, b_local.device)
         if b_local.is_cuda:
             sparse.gather_rows(b_local, self.send_rows, send_buf)      # column slices are read in place
         else:
             torch.index_select(b_local, 0, self.send_rows, out=send_buf)
-        work = _Done
         if self._collective:
-            if async_op and not _through_host(b_halo, self.group):
-                work = dist.all_to_all_single(b_halo, send_buf, self.recv_splits, self.send_splits, group=self.group,
-                                              async_op=True)
-            else:
-                all_to_all_rows(b_halo, send_buf, self.recv_splits, self.send_splits, group=self.group)
+            all_to_all_rows(b_halo, send_buf, self.recv_splits, self.send_splits, group=self.group)
         else:
             b_halo.copy_(send_buf)
-        return (b_halo, work) if async_op else b_halo
+        return b_halo
 
 
 class _Done(object):
     """Stands for the handle of an exchange that has already completed."""
     @staticmethod
     def wait():
+        return True
+
+
+class _AfterEvent(object):
+    """Handle of work enqueued on another stream: ``wait()`` orders the current stream after it."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
         return True
 
 
@@ -310,10 +355,11 @@ def column_chunks(f, chunks, progressive=True):
 class HaloSpmm(object):
     """C_local = A_local . B where every rank receives only the rows of B its shard references.
 
-    With ``chunks`` > 1 the feature columns are cut into that many ranges and the exchange of range
-    i+1 is in flight while the product of range i runs (each output column depends on the same
-    column of B only, and every row still accumulates in storage order, so the result does not
-    change by a bit).  The first range's exchange is the only one the product waits for."""
+    With ``chunks`` > 1 the feature columns are cut into that many ranges whose exchanges are all issued
+    at once and follow each other on the links while the products of the ranges that have arrived run
+    (each output column depends on the same column of B only, and every row still accumulates in
+    storage order, so the result does not change by a bit).  The first range's exchange is the only one
+    the product waits for."""
 
     def __init__(self, shard, f, group=None, spmm=None, csr_factory=None, plan=None, chunks=1):
         self.shard, self.f = shard, f
@@ -331,7 +377,7 @@ class HaloSpmm(object):
     # width shares of the candidate pipelines: how long the first (exposed) exchange is against how
     # much the narrower products cost depends on the ratio of link to memory speed, which differs
     # between 2, 4 and 8 ranks -- so it is measured, not assumed
-    CANDIDATES = ((1,), (1, 3), (1, 1), (1, 1, 2), (1, 1, 2, 4), (1, 1, 1, 1))
+    CANDIDATES = ((1,), (1, 7), (1, 3), (1, 1), (1, 1, 6), (1, 1, 2), (1, 1, 2, 4))
 
     def autotune(self, b_local, reps=2, clock=None):
         """Time every candidate split of the feature columns on this communicator (max over the ranks,
@@ -379,7 +425,8 @@ def column_shares(f, shares):
 
 
 def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None, out_dropout=None):
-    """out = A_local . B with the exchange of column range i+1 in flight during the product of range i.
+    """out = A_local . B over column ranges: every range's exchange is issued at once (HaloPlan.exchange_ranges)
+    and the product of a range starts when its rows have arrived, so only the first range's exchange is exposed.
     ``out_dropout`` (sparse.OutDropout over the full width, index_offset = first local row * width):
     the output is stored already dropped."""
     spmm = spmm or sparse.spmm
@@ -393,13 +440,7 @@ def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None, out_dro
         if out_dropout is not None:
             extra['out_dropout'] = out_dropout
         return spmm(plan.compact, plan.exchange(b_local), relu=relu, out=out, **extra)
-    c0, c1 = ranges[0]
-    pending = plan.exchange(b_local[:, c0:c1], slot=0, async_op=True)
-    for i, (c0, c1) in enumerate(ranges):
-        rows, work = pending
-        if i + 1 < len(ranges):
-            n0, n1 = ranges[i + 1]
-            pending = plan.exchange(b_local[:, n0:n1], slot=(i + 1) & 1, async_op=True)
+    for (c0, c1), (rows, work) in zip(ranges, plan.exchange_ranges(b_local, ranges)):
         work.wait()
         if out_dropout is not None:
             extra['out_dropout'] = out_dropout.columns(c0)

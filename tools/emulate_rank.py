@@ -1,55 +1,139 @@
-"""One rank's share of the row-sharded product, measured on one GPU: rank 0's shard of the scale-24 R-MAT
-graph for 2, 4 and 8 ranks -- rows of B it references, local product at full width and in pipelined
-column ranges, packing of a send buffer.  (No collectives: xGMI time is not part of this.)"""
-import sys, numpy as np, torch
+"""One rank's share of the row-sharded product, measured on ONE GPU through the code the ranks run.
+
+Rank 0's shard of the scale-24 R-MAT graph for 2, 4 and 8 ranks goes through ``dist.halo_product`` with a
+plan whose exchange is a device copy of the bytes the rank would receive (``HaloPlan`` without a
+communicator): packing on the plan's side stream, the copy standing in for the link transfer (it loads
+HBM as sending plus receiving does, it does not take the time a link takes), the products of the column
+ranges on the caller's stream.  Measured per candidate split: the products alone, the whole pipeline, the
+packing and the copy of the first range.  Modelled: the step time with the first range's copy replaced
+by its transfer time over xGMI at the nominal 153 GB/s per link (P - 1 links in use), and the
+strong-scaling efficiency E(P) = T_1 / (P T_P) against the one-GPU product measured in the same run.
+
+    python tools/emulate_rank.py [--scale 24] [--features 256] [--out gpurun_out/r3/rank_emulation.json]
+"""
+import argparse
+import json
 import os
+import sys
+
+import numpy as np
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gcn_amd import sparse, dist as gdist
-scale, f = 24, 256
-n = 1 << scale
-indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
-d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
-vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
-def timed(fn, reps=10):
-    for _ in range(2): fn()
-    torch.cuda.synchronize(); ms=[]
+from gcn_amd import sparse, dist as gdist   # noqa: E402
+
+LINK_GBPS = 153.0
+
+
+def timed(fn, reps=8):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    ms = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); e1.synchronize(); ms.append(e0.elapsed_time(e1))
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
     return float(np.median(ms))
-for world in (2, 4, 8):
-    shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, world)
+
+
+def stand_in_plan(shard, per):
+    """A HaloPlan of one process standing for one rank of ``world``: the compact matrix and the row count of
+    the real plan; the rows it packs are random rows of its own block, as many as the plan references, and
+    the "exchange" copies them into the receive buffer."""
     local = shard.local
     cols = local.indices.to(torch.int64)
     needed = torch.unique(cols)
     new_cols = torch.searchsorted(needed, cols).to(torch.int32)
-    compact = sparse.DeviceCSR(local.n_rows, int(needed.numel()), local.indptr, new_cols, local.values)
-    per = n // world
-    own = int(((needed >= 0) & (needed < per)).sum())
-    n_needed = int(needed.numel())
-    del cols, new_cols
-    halo = sparse.synthetic_dense(n_needed, f, seed=3)
-    out = torch.empty((local.n_rows, f), device='cuda')
-    t_full = timed(lambda: sparse.spmm(compact, halo, out=out))
-    halo64 = [torch.empty((n_needed, 64), device='cuda').copy_(halo[:, i*64:(i+1)*64]) for i in range(4)]
-    def chunks():
-        for i in range(4):
-            sparse.spmm(compact, halo64[i], out=out[:, i*64:(i+1)*64], wide_split=True)
-    t_chunks = timed(chunks)
-    rng = gdist.column_chunks(f, 4)
-    halop = [torch.empty((n_needed, hi-lo), device='cuda').copy_(halo[:, lo:hi]) for lo, hi in rng]
-    def prog():
-        for (lo, hi), hb in zip(rng, halop):
-            sparse.spmm(compact, hb, out=out[:, lo:hi], wide_split=True)
-    t_prog = timed(prog)
-    print('world', world, 'progressive ranges', rng, '%.2f ms' % t_prog, flush=True)
-    # send side: this rank packs about as many rows as it receives from others
-    n_send = n_needed - own
-    b_local = sparse.synthetic_dense(per, f, seed=5)
-    rows = torch.randint(0, per, (n_send,), device='cuda')
-    send = torch.empty((n_send, 64), device='cuda')
-    t_pack = timed(lambda: sparse.gather_rows(b_local[:, 0:64], rows, send))
-    print('world %d: rows/rank %d nnz %d needed %d (%.1f%% of N; own %d) | full-width product %.2f ms | 4 x 64 columns %.2f ms | pack of one 64-col range (%d rows) %.3f ms | received per range %.2f GB'
-          % (world, local.n_rows, local.nnz, n_needed, 100.0*n_needed/n, own, t_full, t_chunks, n_send, t_pack, (n_needed-own)*256/1e9), flush=True)
-    del shard, local, compact, halo, out, halo64, b_local, rows, send, needed
+    plan = gdist.HaloPlan.__new__(gdist.HaloPlan)
+    plan.shard, plan.group = shard, None
+    plan.compact = sparse.DeviceCSR(local.n_rows, int(needed.numel()), local.indptr, new_cols, local.values)
+    plan.n_needed = int(needed.numel())
+    plan._identity, plan._collective, plan._buffers, plan._side = False, False, {}, None
+    own = int(((needed >= shard.row_begin) & (needed < shard.row_end)).sum())
+    plan.send_rows = torch.randint(0, per, (plan.n_needed,), device=local.device)
+    return plan, own
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--scale', type=int, default=24)
+    ap.add_argument('--features', type=int, default=256)
+    ap.add_argument('--out', default=None)
+    args = ap.parse_args()
+    scale, f = args.scale, args.features
+    n = 1 << scale
+    indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    whole = sparse.DeviceCSR(n, n, indptr, indices, vals)
+    b = sparse.synthetic_dense(n, f, seed=7)
+    c = torch.empty((n, f), device='cuda')
+    t1 = timed(lambda: sparse.spmm(whole, b, out=c))
+    del c, whole
     torch.cuda.empty_cache()
+    print('one GPU, whole product: %.2f ms' % t1, flush=True)
+    report = {'scale': scale, 'features': f, 'one_gpu_ms': t1, 'link_gbps': LINK_GBPS, 'worlds': []}
+    for world in (2, 4, 8):
+        per = n // world
+        shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, world)
+        plan, own = stand_in_plan(shard, per)
+        b_local = b[:per]
+        out = torch.empty((per, f), device='cuda')
+        recv_rows = plan.n_needed - own                    # rows that come over the links
+        links = world - 1
+        halo = torch.empty((plan.n_needed, f), device='cuda').copy_(b[:plan.n_needed])
+        t_full = timed(lambda: sparse.spmm(plan.compact, halo, out=out))
+        entry = {'world': world, 'rows_per_rank': per, 'referenced_rows': plan.n_needed,
+                 'referenced_share_of_n': plan.n_needed / n, 'rows_over_links': recv_rows,
+                 'received_gb_per_product': recv_rows * f * 4 / 1e9, 'local_product_full_width_ms': t_full,
+                 'link_total_ms': recv_rows * f * 4 / (links * LINK_GBPS * 1e9) * 1e3, 'splits': []}
+        for shares in gdist.HaloSpmm.CANDIDATES:
+            ranges = gdist.column_shares(f, shares)
+            widths = [hi - lo for lo, hi in ranges]
+
+            def products_alone():
+                for lo, hi in ranges:
+                    sparse.spmm(plan.compact, halo[:, lo:hi], out=out[:, lo:hi], wide_split=f >= 128)
+
+            def pipeline():
+                gdist.halo_product(plan, b_local, out, False, ranges)
+
+            w0 = widths[0]
+            send0, recv0 = plan._buffers_for(w0, 0, b_local.device)
+            t_products = timed(products_alone)
+            t_pipe = timed(pipeline) if len(ranges) > 1 else None
+            t_pack0 = timed(lambda: sparse.gather_rows(b_local[:, :w0], plan.send_rows, send0))
+            t_copy0 = timed(lambda: recv0.copy_(send0))
+            link0 = recv_rows * w0 * 4 / (links * LINK_GBPS * 1e9) * 1e3
+            if t_pipe is None:                 # one range: packing, the whole exchange, then the product
+                t_pipe = timed(lambda: sparse.spmm(plan.compact, plan.exchange(b_local), out=out))
+            modelled = t_pipe - t_copy0 + link0
+            entry['splits'].append({'widths': widths, 'products_alone_ms': t_products, 'pipeline_ms': t_pipe,
+                                    'pack_first_range_ms': t_pack0, 'copy_first_range_ms': t_copy0,
+                                    'link_first_range_ms': link0, 'modelled_step_ms': modelled,
+                                    'modelled_efficiency': t1 / (world * modelled)})
+            print('world %d widths %-18s products %.2f  pipeline %.2f  pack0 %.3f  copy0 %.3f  link0 %.3f  -> T_P %.2f ms, E = %.3f'
+                  % (world, widths, t_products, t_pipe, t_pack0, t_copy0, link0, modelled, t1 / (world * modelled)),
+                  flush=True)
+            plan.drop_buffers()
+            torch.cuda.empty_cache()
+        best = min(entry['splits'], key=lambda s_: s_['modelled_step_ms'])
+        entry['best'] = best
+        report['worlds'].append(entry)
+        print('world %d: references %.1f%% of N, full-width local product %.2f ms, links busy %.2f ms per product; '
+              'best split %s: E(%d) = %.3f' % (world, 100.0 * plan.n_needed / n, t_full, entry['link_total_ms'],
+                                               best['widths'], world, best['modelled_efficiency']), flush=True)
+        del shard, plan, halo, out, b_local
+        torch.cuda.empty_cache()
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, 'w') as fh:
+            json.dump(report, fh, indent=1)
+
+
+if __name__ == '__main__':
+    main()
