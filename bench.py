@@ -97,7 +97,10 @@ def measured_traffic(kernel, scale, edge_factor, f, world):
     with open(path) as fh:
         for rec in json.load(fh):
             if (rec['kernel'], rec['scale'], rec['edge_factor'], rec['features']) == (kernel, scale, edge_factor, f):
-                if rec.get('spmm_hip_sha256') != kernel_source_hash():
+                # the record is quoted for the kernel source it was taken on, and only while the library that
+                # is loaded was built from the sources on disk (the hash compiled into it says so)
+                from gcn_amd import _lib
+                if rec.get('spmm_hip_sha256') != kernel_source_hash() or _lib.build_hash() != _lib.source_hash():
                     return None
                 return rec
     return None

@@ -37,6 +37,7 @@ _psz = ctypes.POINTER(ctypes.c_size_t)
 SIGNATURES = {
     'gcn_version': [],
     'gcn_last_error_string': [],
+    'gcn_build_hash': [],
     'gcn_coo_to_csr_bound': [_i64, _i64, _int, _pi64, _psz],
     'gcn_coo_to_csr': [_i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'gcn_rows_to_indptr': [_i64, _i64, _vp, _vp, _vp],
@@ -113,9 +114,28 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == 'gcn_last_error_string' else ctypes.c_int
+        fn.restype = ctypes.c_char_p if name in ('gcn_last_error_string', 'gcn_build_hash') else ctypes.c_int
     _lib = lib
     return lib
+
+
+def build_hash():
+    """sha256 of the sources the loaded library was built from."""
+    return load().gcn_build_hash().decode('ascii')
+
+
+def source_hash():
+    """The same hash over the source files on disk: equal to ``build_hash()`` unless the library is stale."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, 'csrc')
+    names = sorted(os.path.basename(p) for ext in ('*.hip', '*.cpp', '*.h') for p in glob.glob(os.path.join(csrc, ext)))
+    names.remove('asan_check.cpp')                 # the sanitizer driver is not part of the library
+    digest = hashlib.sha256()
+    for path in [os.path.join(csrc, n) for n in names] + [os.path.join(os.path.dirname(_HERE), 'include', 'gcn_hip.h')]:
+        with open(path, 'rb') as fh:
+            digest.update(fh.read())
+    return digest.hexdigest()
 
 
 def check(status):

@@ -1,0 +1,169 @@
+// Host-side sanitizer run of libgcn_hip's sources (`make -C gcn_amd/csrc asan`): this file and the library's
+// sources are compiled into ONE executable with AddressSanitizer and UndefinedBehaviorSanitizer on the host
+// code (device code is built as usual and never runs here).  It needs no GPU: it walks the host-only parts of
+// the C ABI -- the size queries, the argument validation of every entry point, which returns before any HIP
+// call, the error text -- and the host half of plan creation (the long-row tables) on random row lengths.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "common.h"
+
+static int g_failures = 0;
+#define EXPECT(cond)                                                          \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            fprintf(stderr, "%s:%d: check failed: %s\n", __FILE__, __LINE__, #cond); \
+            ++g_failures;                                                     \
+        }                                                                     \
+    } while (0)
+
+static void size_queries() {
+    int64_t cap = 0;
+    size_t bytes = 0;
+    for (int64_t n : {0ll, 1ll, 1000ll, 1ll << 20}) {
+        EXPECT(gcn_coo_to_csr_bound(n, 3 * n, GCN_ADD_SELF_LOOPS, &cap, &bytes) == GCN_OK && cap >= 4 * n && bytes > 0);
+        EXPECT(gcn_coo_to_csr_bound(n, 3 * n, GCN_BINARY, &cap, &bytes) == GCN_OK);
+        EXPECT(gcn_csr_transpose_bound(n, n, 5 * n, &bytes) == GCN_OK && bytes > 0);
+        EXPECT(gcn_degree_order_bound(n, &bytes) == GCN_OK);
+        EXPECT(gcn_csr_relabel_bound(n, 5 * n, 1, &bytes) == GCN_OK);
+        EXPECT(gcn_rmat_csr_rows_bound(7 * n, &bytes) == GCN_OK);
+        EXPECT(gcn_gemm_tn_workspace_bytes(n, 256, 256, &bytes) == GCN_OK);
+        EXPECT(gcn_gemm_tn_workspace_bytes(n, 7, 16, &bytes) == GCN_OK);
+        EXPECT(gcn_loss_summary_workspace_bytes(n, 1433 * 16 + 16 * 7, &bytes) == GCN_OK);
+    }
+    EXPECT(gcn_rmat_csr_bound(20, 16, GCN_ADD_SELF_LOOPS, &cap, &bytes) == GCN_OK && cap == (33ll << 20));
+    EXPECT(gcn_rmat_csr_bound(0, 16, 0, &cap, &bytes) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_coo_to_csr_bound(-1, 0, 0, &cap, &bytes) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_coo_to_csr_bound(1, 1, 0, nullptr, &bytes) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_version() >= 100 && strlen(gcn_build_hash()) == 64);
+}
+
+static void argument_validation() {
+    gcn_spmm_plan* plan = nullptr;
+    float x[16] = {0};
+    int64_t ip[2] = {0, 0};
+    EXPECT(gcn_spmm_plan_create(-1, 1, 0, ip, &plan, nullptr) == GCN_ERR_BAD_ARG && plan == nullptr);
+    EXPECT(strstr(gcn_last_error_string(), "bad shape") != nullptr);
+    EXPECT(gcn_spmm_plan_create(1, 1, 0, nullptr, &plan, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_plan_create(1, 1, 0, ip, nullptr, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_plan_create_split(1, 1, 0, ip, 5, &plan, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_plan_create_split(1, 1, 0, ip, 5000, &plan, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_plan_destroy(nullptr) == GCN_OK);
+    EXPECT(gcn_spmm_plan_set_timing(nullptr, 1) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_plan_set_lds_hub_rows(nullptr, 1) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_plan_set_hot_columns(nullptr, 1) == GCN_ERR_BAD_ARG);
+    int64_t info[4];
+    size_t bytes = 0;
+    EXPECT(gcn_spmm_plan_info(nullptr, info) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_plan_workspace_bytes(nullptr, 4, &bytes) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_csr_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, x, 4, 0, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_csr_f32_noalloc(nullptr, ip, nullptr, nullptr, 4, x, 4, x, 4, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_csr_add_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, nullptr, 4, x, 4, 0, nullptr, 0, nullptr) ==
+           GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_csr_dropout_f32(nullptr, ip, nullptr, nullptr, nullptr, 4, x, 4, x, 4, 0, 0.0f, 1, 1, nullptr,
+                                    nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_csr_out_dropout_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, x, 4, 0, 0.5f, 1, 1, nullptr, 0, 2,
+                                        nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_f32(4, 4, 4, nullptr, 2, nullptr, 4, 0, nullptr, 4, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_f32(4, 4, 4, nullptr, 4, nullptr, 4, 0, nullptr, 4, 64, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_f32(4, 4, 4, nullptr, 4, nullptr, 4, 0, nullptr, 4, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_f32(0, 4, 4, nullptr, 4, nullptr, 4, 0, nullptr, 4, 0, nullptr) == GCN_OK);
+    EXPECT(gcn_gemm_gated_f32(4, 4, 4, x, 4, x, 4, 0, x, 4, 0.0f, x, 4, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_out_dropout_f32(4, 4, 4, x, 4, x, 4, 0, x, 4, 0, 1.5f, 1, 1, nullptr, 0, 4, nullptr, nullptr) ==
+           GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_out_dropout_f32(4, 4, 4, x, 4, x, 4, 0, x, 4, 0, 0.5f, 1, 1, nullptr, 0, 2, nullptr, nullptr) ==
+           GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_tn_f32(4, 4, 4, x, 2, x, 4, x, 4, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_dropout_f32(4, 4, nullptr, 4, nullptr, 0, nullptr, 4, 0.0f, 1, 1, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_dropout_f32(4, 4, nullptr, 4, nullptr, 0, nullptr, 4, 0.5f, 1, 1, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gather_rows_f32(4, 4, 4, nullptr, 2, nullptr, nullptr, 4, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_coo_to_csr(-1, 1, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                          nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_rows_to_indptr(-1, 0, nullptr, nullptr, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_row_sums(-1, nullptr, nullptr, nullptr, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_degree_scale(4, nullptr, 0, nullptr, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_normalize_adj(4, 4, nullptr, nullptr, nullptr, nullptr, 7, nullptr, nullptr, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_row_normalize(4, 4, ip, x, 3, x, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_csr_transpose(4, 4, 4, nullptr, nullptr, nullptr, 4, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                             nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_degree_order(4, nullptr, nullptr, nullptr, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_csr_relabel(-1, 4, 4, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_check_indices(-1, nullptr, 4, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_check_indices(0, nullptr, 4, nullptr) == GCN_OK);
+    EXPECT(gcn_rmat_csr(0, 16, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    int64_t keys = 0;
+    EXPECT(gcn_rmat_rows_count(10, 16, 1, 64, 0, 8, &keys, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_rmat_rows_count(10, 16, 1, 0, 8, 4, &keys, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_rmat_csr_rows(10, 16, 1, 0, 0, 8, -1, nullptr, nullptr, nullptr, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_fill_synthetic_f32(-1, 1, nullptr, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_fill_synthetic_range_f32(0, 0, 1, nullptr, nullptr) == GCN_OK);
+    EXPECT(gcn_softmax_xent_f32(-1, 4, nullptr, 4, nullptr, 4, nullptr, 1.0f, nullptr, nullptr, 4, nullptr) != GCN_OK);
+    EXPECT(gcn_adam_f32(-1, nullptr, nullptr, nullptr, nullptr, 0.1f, nullptr, 0.9f, 0.999f, 1e-8f, 0.0f, nullptr) != GCN_OK);
+    EXPECT(gcn_loss_summary_f32(-1, nullptr, 0, nullptr, 0.0f, nullptr, 0, nullptr, nullptr) != GCN_OK);
+    // the exchange entry points: every argument check comes before RCCL is opened
+    void* comm = nullptr;
+    char id[128] = {0};
+    int64_t counts[1] = {0};
+    EXPECT(gcn_comm_unique_id(nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_comm_init_rank(nullptr, 1, id, 0) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_comm_init_rank(&comm, 0, id, 0) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_comm_init_rank(&comm, 2, id, 2) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_comm_init_rank(&comm, 1, nullptr, 0) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_comm_destroy(nullptr) == GCN_OK);
+    EXPECT(gcn_allgather_rows_f32(nullptr, x, x, 1, 4, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_exchange_rows_f32(nullptr, x, counts, x, counts, 4, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(strlen(gcn_last_error_string()) > 0);
+}
+
+static void long_row_tables() {
+    std::mt19937_64 rng(7);
+    for (int trial = 0; trial < 200; ++trial) {
+        const size_t count = (size_t)(rng() % 300);
+        const int64_t split0 = 16 + (int64_t)(rng() % 300);
+        std::vector<int32_t> rows(count);
+        std::vector<int64_t> starts(count), ends(count);
+        // distinct row numbers in a shuffled order (the collecting kernel's atomics give any order)
+        std::vector<int32_t> ids(count);
+        for (size_t i = 0; i < count; ++i) ids[i] = (int32_t)(i * 3 + (rng() % 3));
+        for (size_t i = count; i > 1; --i) std::swap(ids[i - 1], ids[rng() % i]);
+        for (size_t i = 0; i < count; ++i) {
+            rows[i] = ids[i];
+            starts[i] = (int64_t)(rng() % (1ll << 40));
+            ends[i] = starts[i] + split0 + 1 + (int64_t)(rng() % 5000);
+        }
+        for (int64_t split : {split0, split0 * 4}) {
+            const int64_t chunk_len = (trial & 1) ? split : std::max<int64_t>(16, split / 4);
+            gcn::LongTableHost t;
+            gcn::build_long_table(rows, starts, ends, split, chunk_len, &t);
+            EXPECT(t.long_chunk.size() == t.long_row.size() + 1);
+            EXPECT(t.long_chunk.empty() ? false : (int64_t)t.chunk_long.size() == t.long_chunk.back());
+            size_t expected = 0;
+            for (size_t i = 0; i < count; ++i) expected += (ends[i] - starts[i] > split) ? 1 : 0;
+            EXPECT(t.long_row.size() == expected);
+            for (size_t i = 0; i + 1 < t.long_row.size(); ++i) EXPECT(t.long_row[i] < t.long_row[i + 1]);
+            for (size_t i = 0; i < t.long_row.size(); ++i) {
+                size_t src = 0;
+                while (rows[src] != t.long_row[i]) ++src;
+                const int64_t len = ends[src] - starts[src];
+                const int64_t n_chunks = t.long_chunk[i + 1] - t.long_chunk[i];
+                EXPECT(n_chunks == (len + chunk_len - 1) / chunk_len);
+                for (int64_t c = t.long_chunk[i]; c < t.long_chunk[i + 1]; ++c) EXPECT(t.chunk_long[(size_t)c] == (int32_t)i);
+            }
+        }
+    }
+}
+
+int main() {
+    size_queries();
+    argument_validation();
+    long_row_tables();
+    if (g_failures) {
+        fprintf(stderr, "asan_check: %d check(s) failed\n", g_failures);
+        return 1;
+    }
+    printf("asan_check ok\n");
+    return 0;
+}

@@ -28,6 +28,8 @@ struct Rccl {
     int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t);
     int (*GroupStart)();
     int (*GroupEnd)();
+    int (*CommAbort)(comm_t);
+    int (*GetVersion)(int*);
     const char* (*GetErrorString)(int);
 };
 constexpr int kFloat32 = 7;
@@ -63,8 +65,25 @@ static int rccl(const Rccl** out) {
         GCN_SYM(Recv, "ncclRecv")
         GCN_SYM(GroupStart, "ncclGroupStart")
         GCN_SYM(GroupEnd, "ncclGroupEnd")
+        GCN_SYM(CommAbort, "ncclCommAbort")
+        GCN_SYM(GetVersion, "ncclGetVersion")
         GCN_SYM(GetErrorString, "ncclGetErrorString")
 #undef GCN_SYM
+        // The slice above (ncclFloat32 = 7, the 128-byte id passed by value) is the ABI of NCCL 2.x, which
+        // every RCCL release so far follows; a library that reports another major version is refused rather
+        // than called with a layout it may not have.  Version code: major * 1000 + ... up to 2.8, major *
+        // 10000 + ... from 2.9 on.
+        int version = 0;
+        if (r.GetVersion(&version) != 0 || version <= 0) {
+            dlclose(h);
+            return fail(GCN_ERR_RCCL, "ncclGetVersion failed");
+        }
+        const int major = version >= 10000 ? version / 10000 : version / 1000;
+        if (major != 2) {
+            dlclose(h);
+            return fail(GCN_ERR_RCCL, "RCCL reports version code %d (major %d): only the NCCL 2.x ABI is supported",
+                        version, major);
+        }
         g_rccl = r;
     }
     *out = &g_rccl;
@@ -159,8 +178,15 @@ int gcn_exchange_rows_f32(void* comm, const float* send, const int64_t* send_row
         r_at += recv_rows_host[p];
     }
     const int end = lib->GroupEnd();
-    if (first_error) return fail(GCN_ERR_RCCL, "ncclSend/ncclRecv failed: %s", lib->GetErrorString(first_error));
-    if (end) return fail(GCN_ERR_RCCL, "ncclGroupEnd failed: %s", lib->GetErrorString(end));
+    if (first_error || end) {
+        // Some of this rank's pairs were never posted (or the group failed): the peers' matching calls
+        // would wait for them for ever.  Abort the communicator -- that ends the peers' operations with an
+        // error instead of a hang, and frees the communicator -- and report it: after GCN_ERR_RCCL the
+        // handle is dead (no further call on it, gcn_comm_destroy included).
+        (void)lib->CommAbort((comm_t)comm);
+        return fail(GCN_ERR_RCCL, "%s failed: %s; the communicator was aborted and cannot be used again",
+                    first_error ? "ncclSend/ncclRecv" : "ncclGroupEnd", lib->GetErrorString(first_error ? first_error : end));
+    }
     return GCN_OK;
 }
 

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "../../include/gcn_hip.h"
 
 namespace gcn {
@@ -77,6 +79,15 @@ __host__ __device__ __forceinline__ uint64_t scramble_id(uint64_t v, int bits, u
     x ^= x >> sh;
     return x;
 }
+
+// long-row tables of a product plan as plan creation builds them on the host (spmm.hip)
+struct LongTableHost {
+    std::vector<int32_t> long_row;    // rows longer than the split threshold, ascending
+    std::vector<int64_t> long_chunk;  // [n_long + 1] first chunk of each such row
+    std::vector<int32_t> chunk_long;  // [n_chunks] slot in long_row of each chunk
+};
+void build_long_table(const std::vector<int32_t>& rows, const std::vector<int64_t>& starts,
+                      const std::vector<int64_t>& ends, int64_t split, int64_t chunk_len, LongTableHost* out);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -29,6 +29,13 @@ extern "C" {
 
 int gcn_version(void) { return 100; }
 
+// sha256 of the sources this library was built from (written by the Makefile)
+const char* gcn_build_hash(void) {
+    return
+#include "build_hash.inc"
+        ;
+}
+
 const char* gcn_last_error_string(void) { return gcn::g_error; }
 
 }  // extern "C"

@@ -978,6 +978,33 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
     return vec4 ? launch_by_width<4, DROPOUT>(a) : launch_by_width<1, DROPOUT>(a);
 }
 
+// Host half of plan creation: from the rows longer than the smaller threshold (any order, as the collecting
+// kernel's atomics left them) the table of the rows longer than `split` in ascending row order, each cut in
+// chunks of chunk_len entries.  long_chunk has one more entry than long_row (the total closes it).
+void build_long_table(const std::vector<int32_t>& rows, const std::vector<int64_t>& starts,
+                      const std::vector<int64_t>& ends, int64_t split, int64_t chunk_len, LongTableHost* out) {
+    const size_t count = rows.size();
+    std::vector<int64_t> order(count);
+    for (size_t i = 0; i < count; ++i) order[i] = (int64_t)i;
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return rows[x] < rows[y]; });
+    out->long_row.clear();
+    out->long_chunk.clear();
+    out->chunk_long.clear();
+    int64_t total = 0;
+    for (size_t i = 0; i < count; ++i) {
+        const int64_t o = order[i];
+        const int64_t len = ends[o] - starts[o];
+        if (len <= split) continue;
+        const int32_t slot = (int32_t)out->long_row.size();
+        out->long_row.push_back(rows[o]);
+        out->long_chunk.push_back(total);
+        const int64_t nch = ceil_div(len, chunk_len);
+        out->chunk_long.insert(out->chunk_long.end(), (size_t)nch, slot);
+        total += nch;
+    }
+    out->long_chunk.push_back(total);
+}
+
 }  // namespace gcn
 
 using namespace gcn;
@@ -1082,27 +1109,13 @@ int gcn_spmm_plan_create_split(int64_t n_rows, int64_t n_cols, int64_t nnz, cons
             PLAN_TRY(hipMemcpy(rows.data(), d_rows, count * sizeof(int32_t), hipMemcpyDeviceToHost));
             PLAN_TRY(hipMemcpy(starts.data(), d_starts, count * sizeof(int64_t), hipMemcpyDeviceToHost));
             PLAN_TRY(hipMemcpy(ends.data(), d_ends, count * sizeof(int64_t), hipMemcpyDeviceToHost));
-            std::vector<int64_t> order(count);
-            for (size_t i = 0; i < count; ++i) order[i] = (int64_t)i;
-            std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return rows[x] < rows[y]; });
             for (int t = 0; t < 2; ++t) {
-                const int64_t split = p->split[t];
-                std::vector<int32_t> long_row;
-                std::vector<int64_t> long_chunk;
-                std::vector<int32_t> chunk_long;
-                int64_t total = 0;
-                for (size_t i = 0; i < count; ++i) {
-                    const int64_t o = order[i];
-                    const int64_t len = ends[o] - starts[o];
-                    if (len <= split) continue;
-                    const int32_t slot = (int32_t)long_row.size();
-                    long_row.push_back(rows[o]);
-                    long_chunk.push_back(total);
-                    const int64_t nch = ceil_div(len, p->chunk_len ? (int64_t)p->chunk_len : split);
-                    chunk_long.insert(chunk_long.end(), (size_t)nch, slot);
-                    total += nch;
-                }
-                long_chunk.push_back(total);
+                LongTableHost host;
+                build_long_table(rows, starts, ends, p->split[t], p->chunk_len ? (int64_t)p->chunk_len : p->split[t], &host);
+                const std::vector<int32_t>& long_row = host.long_row;
+                const std::vector<int64_t>& long_chunk = host.long_chunk;
+                const std::vector<int32_t>& chunk_long = host.chunk_long;
+                const int64_t total = long_chunk.back();
                 const size_t nl = long_row.size();
                 if (nl == 0) continue;
                 gcn_spmm_plan::LongTable& lt = p->table[t];

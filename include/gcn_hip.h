@@ -51,6 +51,11 @@ typedef enum {
 
 int gcn_version(void);
 const char* gcn_last_error_string(void);
+/* sha256 (hex) of the concatenation, in byte order of the file names, of gcn_amd/csrc/{*.cpp,*.h,*.hip}
+ * followed by include/gcn_hip.h, taken when the library was built: tells a stale prebuilt library from
+ * one built from the sources beside it (gcn_amd._lib.source_hash() computes the same over the files on
+ * disk).  No counterpart in the reference, which has nothing to build. */
+const char* gcn_build_hash(void);
 
 /* ------------------------------------------------------------------------- *
  * Graph preprocessing -- integer work, bit-exact.                            *
@@ -347,7 +352,10 @@ int gcn_comm_destroy(void* comm);
 int gcn_allgather_rows_f32(void* comm, const float* send, float* recv, int64_t rows_per_rank, int64_t f, void* stream);
 /* Exchange of the referenced rows only: send holds, rank after rank, send_rows_host[p] rows of f floats
  * for rank p; recv receives recv_rows_host[p] rows from rank p, rank after rank (host arrays of n_ranks
- * counts).  One grouped send/receive pair per peer, so every xGMI link carries its own pair at once. */
+ * counts).  One grouped send/receive pair per peer, so every xGMI link carries its own pair at once.
+ * If a send or receive cannot be posted the communicator is aborted (so that the peers' matching calls
+ * end with an error instead of waiting for ever) and GCN_ERR_RCCL is returned: after that status the
+ * communicator must not be used again.  gcn_comm_destroy after an abort: do not call it. */
 int gcn_exchange_rows_f32(void* comm, const float* send, const int64_t* send_rows_host, float* recv,
                           const int64_t* recv_rows_host, int64_t f, void* stream);
 

@@ -39,6 +39,13 @@ def test_library_exports_every_symbol():
     assert loaded.gcn_last_error_string() is not None
 
 
+def test_library_was_built_from_the_sources_on_disk():
+    """A stale prebuilt library fails here: the hash compiled into it is the one of the files beside it."""
+    from gcn_amd import _lib
+    assert len(_lib.build_hash()) == 64
+    assert _lib.build_hash() == _lib.source_hash(), 'gcn_amd/libgcn_hip.so is older than its sources: run make -C gcn_amd/csrc'
+
+
 def test_status_codes_map_to_the_reference_exception_types():
     import pytest
     from gcn_amd import _lib

@@ -93,6 +93,37 @@ def test_whole_panel_form_gives_the_bits_of_the_guarded_form(oracle, m, n, k, tr
     assert torch.equal(c_wide[:, 3:3 + n], torch.where(gate > 0, guarded * 2, torch.zeros_like(guarded)))
 
 
+def test_relu_store_of_both_forms_on_nan_infinities_and_underflow():
+    """The panel kernel's ReLU is one hardware maximum against 0, the guarded kernel's a compare and select.
+    Rows 0..127 go through the first, rows 128..191 (duplicates of rows 0..63) through the second: they must
+    hold the same bits where the accumulators are NaN (inf - inf, 0 * inf), +inf, -inf, a negative value that
+    underflows to zero, and ordinary values of either sign."""
+    import torch
+    from gcn_amd import sparse
+    m, n, k = 192, 128, 32
+    a = torch.zeros((m, k), device='cuda')
+    g = torch.Generator(device='cuda').manual_seed(4)
+    a[:128] = torch.rand((128, k), device='cuda', generator=g) * 2 - 1
+    a[0, 0], a[0, 1] = float('inf'), float('-inf')           # inf - inf against equal-sign columns of B -> NaN
+    a[1, 0] = float('inf')                                     # +-inf, and 0 * inf = NaN where B is 0
+    a[2, 0] = float('-inf')
+    a[3] = 0.0
+    a[3, 0] = -1e-30                                           # times 1e-30 in B: a negative product that underflows
+    a[4] = 0.0                                                 # an all-zero row: accumulators stay +0
+    a[128:] = a[:64]
+    b = torch.rand((k, n), device='cuda', generator=g) * 2 - 1
+    b[0, :8] = 0.0
+    b[0, 8:16] = 1e-30
+    out = sparse.gemm(a, b, relu=True)
+    plain = sparse.gemm(a, b)
+    assert bool(torch.isnan(plain[0]).any()) and bool(torch.isinf(plain[1]).any()) and bool(torch.isinf(plain[2]).any())
+    assert torch.equal(out[:64].view(torch.int32), out[128:].view(torch.int32))
+    assert torch.equal(plain[:64].view(torch.int32), plain[128:].view(torch.int32))
+    # and both are `v > 0 ? v : 0` of the plain product, bit for bit (NaN and -0 become +0)
+    want = torch.where(plain > 0, plain, torch.zeros_like(plain))
+    assert torch.equal(out.view(torch.int32), want.view(torch.int32))
+
+
 @pytest.mark.parametrize('pitch', [(1 << 22) - 64, (1 << 22) + 64])
 def test_whole_panel_form_at_the_largest_row_pitch_it_takes(oracle, pitch):
     """The kernel without guards addresses a tile with 32-bit byte offsets: it takes operands whose 128 rows

@@ -192,3 +192,25 @@ def test_lds_staged_hub_rows_change_no_bit(big_hat, oracle, f):
     ordered.plan.set_lds_hub_rows(256)
     assert torch.equal(sparse.spmm(ordered, wide[:, :f]), plain)
     ordered.plan.set_lds_hub_rows(0)
+
+
+def test_lds_hub_rows_on_an_empty_matrix():
+    """A large matrix without entries reads no row of B -- the operand may even be absent -- so a plan with
+    LDS hub rows switched on must not stage any: the product is all zeros."""
+    import ctypes
+    import torch
+    from gcn_amd import _lib, sparse
+    n, f = 1 << 20, 16
+    empty = sparse.DeviceCSR(n, n, torch.zeros(n + 1, dtype=torch.int64, device='cuda'),
+                             torch.zeros(0, dtype=torch.int32, device='cuda'), torch.zeros(0, device='cuda'))
+    empty.plan.set_lds_hub_rows(512)
+    b = sparse.synthetic_dense(n, f, seed=2)
+    out = torch.full((n, f), float('nan'), device='cuda')
+    sparse.spmm(empty, b, out=out)
+    assert bool((out == 0).all())
+    out.fill_(float('nan'))
+    # the C ABI accepts a null operand for a matrix without entries
+    _lib.call('gcn_spmm_csr_f32', empty.plan.handle, ctypes.c_void_p(empty.indptr.data_ptr()), None, None, f, None, f,
+              ctypes.c_void_p(out.data_ptr()), f, 0, None, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert bool((out == 0).all())

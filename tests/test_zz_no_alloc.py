@@ -30,6 +30,15 @@ def _csr(n, ip, ix, v):
                             torch.as_tensor(v).cuda())
 
 
+def _device_free_bytes():
+    """Free device memory as the HIP runtime itself reports it (hipMemGetInfo through ctypes): it sees every
+    allocation of the process, those made inside libgcn_hip.so included, which torch's counters do not."""
+    hip = ctypes.CDLL('libamdhip64.so')
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
 def test_no_alloc_entry_point_equals_the_workspace_one(oracle):
     import torch
     from gcn_amd import _lib, sparse
@@ -60,10 +69,12 @@ def test_no_alloc_entry_point_equals_the_workspace_one(oracle):
     out2 = torch.full_like(ref2, float('nan'))
     torch.cuda.synchronize()
     before = torch.cuda.memory_allocated()
+    free_before = _device_free_bytes()
     sparse.spmm_noalloc(big, b1, out1)
     sparse.spmm_noalloc(small, b2, out2)                 # smaller input, right after: stale partial rows beyond it
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert _device_free_bytes() == free_before           # nor did the library allocate behind torch's back
     assert torch.equal(out1, ref1)
     assert torch.equal(out2, ref2)
     # and the other way round, with the ReLU epilogue, into a column slice of a wider matrix
@@ -104,3 +115,35 @@ def test_no_alloc_entry_point_equals_the_workspace_one(oracle):
     fresh = _csr(n2, ip2, ix2, v2)
     with pytest.raises(ValueError, match='plan'):
         sparse.spmm_noalloc(fresh, b2, out2)
+
+
+def test_no_alloc_entry_point_under_stream_capture():
+    """The use the entry point is documented for: recorded once in a HIP graph on a matrix whose long rows
+    go through the library's scratch array, replayed with new contents of B.  An allocation, a free or a
+    synchronisation inside the call would make the capture fail; every replay must give the bits of the
+    eager product."""
+    import torch
+    from gcn_amd import sparse
+    n = 1 << 17
+    ip, ix = sparse.rmat_csr(17, 16, seed=42, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(ip, None), 'sym')
+    v = sparse.normalize_values(ip, ix, None, d, 'sym', want64=False)[1]
+    a = sparse.DeviceCSR(n, n, ip, ix, v)
+    assert a.plan.n_chunks > 1000                                   # made before the capture: plan creation allocates
+    f = 64
+    b_static = sparse.synthetic_dense(n, f, seed=1)
+    out_static = torch.full((n, f), float('nan'), device='cuda')
+    sparse.spmm_noalloc(a, b_static, out_static)                    # first call outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sparse.spmm_noalloc(a, b_static, out_static, relu=True)
+    for seed in (5, 6):
+        b_new = sparse.synthetic_dense(n, f, seed=seed)
+        expected = sparse.spmm(a, b_new, relu=True)
+        b_static.copy_(b_new)
+        out_static.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_static, expected)
+    del graph
