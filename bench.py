@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument('--features', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-epoch', action='store_true', help='skip the Planetoid epoch-time leg')
+    ap.add_argument('--no-configs', action='store_true',
+                    help='skip the other BASELINE configurations (scale 22 F=512, PubMed smoothing, narrow widths)')
     ap.add_argument('--chunks', type=int, default=4,
                     help='N>1: ranges of feature columns the exchange is pipelined over (1 = no overlap)')
     ap.add_argument('--no-autotune', action='store_true',
@@ -106,6 +108,24 @@ def measured_traffic(kernel, scale, edge_factor, f, world):
     return None
 
 
+def ranks_seen(sharded, rank, dev):
+    """Who took part, as the communicator itself reports it: the world size of the process group, its
+    backend, and the device every rank computes on (index, name and, where the runtime gives one, the
+    device's uuid), gathered over the group -- so that a record of an N-GPU run can be checked for N
+    distinct GPUs behind N RCCL ranks."""
+    props = torch.cuda.get_device_properties(dev)
+    mine = {'rank': rank, 'device_index': dev.index, 'name': props.name, 'uuid': str(getattr(props, 'uuid', None)),
+            'pid': os.getpid()}
+    if not sharded:
+        return {'world_size': 1, 'backend': None, 'devices': [mine], 'distinct_devices': 1}
+    import torch.distributed as dist
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    distinct = len({(d['device_index'], d['uuid']) for d in everyone})
+    return {'world_size': dist.get_world_size(), 'backend': dist.get_backend(), 'devices': everyone,
+            'distinct_devices': distinct}
+
+
 def host_description():
     """Core counts and CPU model of the host the CPU baseline runs on."""
     model = None
@@ -148,7 +168,7 @@ def planetoid_epoch_ms(name, epochs=60, hip_graph=False):
             'train_step': 'one HIP graph' if hip_graph else 'eager launches'}
 
 
-def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, classes=16, chunks=4):
+def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, classes=16, chunks=4):
     """One training step (forward + backward + Adam: the region train.py:203-205 times) of a 2-layer GCN
     features -> hidden -> classes on the bench graph, rows sharded over the ranks, in two forms:
 
@@ -171,29 +191,31 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=3, warmup=2, hidden=256, cl
                            dropout=0.5, seed=123, chunks=chunks, **form)
         for _ in range(warmup):
             model.train_step(x_local, labels, mask)
-        if group_world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        per_step = []
+        for _ in range(steps):                      # every step bracketed like the whole run: barrier + synchronize
+            if group_world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             loss = model.train_step(x_local, labels, mask)
-        if group_world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        if group_world > 1:
-            t = torch.tensor([ms], dtype=torch.float64, device=x_local.device)
+            torch.cuda.synchronize()
+            per_step.append((time.perf_counter() - t0) * 1e3)
+        t = torch.tensor(per_step, dtype=torch.float64, device=x_local.device)
+        if group_world > 1:                          # a step takes as long as its slowest rank
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            ms = float(t.item())
+        per_step = t.cpu().numpy()
         described = (model.aggregate_first, model.receptive_field and model.aggregate_first)
         loss = float(loss)
         del model
         torch.cuda.empty_cache()
-        return ms, loss, described
+        return float(np.median(per_step)), float(per_step.min()), float(per_step.mean()), loss, described
 
-    ref_ms, ref_loss, _ = timed(aggregate_first=False, receptive_field=False, labelled_logits_only=False)
-    ms, loss, (aggregated, pruned) = timed()
-    return {'reference_order_ms': ref_ms, 'reference_order_loss': ref_loss, 'ms': ms, 'loss': loss,
+    ref_ms, ref_min, ref_mean, ref_loss, _ = timed(aggregate_first=False, receptive_field=False,
+                                                   labelled_logits_only=False)
+    ms, ms_min, ms_mean, loss, (aggregated, pruned) = timed()
+    return {'reference_order_ms': ref_ms, 'reference_order_ms_min': ref_min, 'reference_order_ms_mean': ref_mean,
+            'reference_order_loss': ref_loss, 'ms': ms, 'ms_min': ms_min, 'ms_mean': ms_mean, 'loss': loss,
+            'statistic': 'median of %d timed steps (min and mean beside it), each between synchronisations' % steps,
             'layers': [int(x_local.shape[1]), hidden, classes], 'steps': steps,
             'what': 'forward + backward + Adam, dropout 0.5, one labelled node in 64, rows/%d.  reference_order_ms: '
                     "every layer as A.(X'.W) over all rows (gcn/layers.py:198-202).  ms: first layer as %s%s" % (
@@ -250,6 +272,153 @@ def cpu_baseline(a, b_dev, c_dev, row_stride):
     return base, allcores, check
 
 
+def _median_min(ms):
+    return float(np.median(ms)), float(np.min(ms))
+
+
+def product_point(label, a, f, steps=10, warmup=2, cpu_rows=0):
+    """One more point of the product: C = a . B for a seeded B of f columns, resident in HBM.  Per launch
+    the row kernel's own duration (HIP events recorded by the library on the launch stream) and the roofline
+    triple on the algorithmic bytes."""
+    from gcn_amd import sparse
+    b = sparse.synthetic_dense(a.n_cols, f, seed=7)
+    c = torch.empty((a.n_rows, f), dtype=torch.float32, device=b.device)
+    a.plan.set_timing(True)
+    for _ in range(warmup):
+        sparse.spmm(a, b, out=c)
+    torch.cuda.synchronize()
+    wall, kern = [], []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        sparse.spmm(a, b, out=c)
+        row_ms, red_ms = a.plan.last_timing()          # waits for the product
+        wall.append((time.perf_counter() - t0) * 1e3)
+        kern.append(row_ms)
+    a.plan.set_timing(False)
+    del b, c
+    torch.cuda.empty_cache()
+    algo = bytes_min(a.n_rows, a.n_cols, a.nnz, f)
+    gathered = bytes_gather(a.n_rows, a.nnz, f)
+    k_med, k_min = _median_min(kern)
+    w_med, w_min = _median_min(wall)
+    achieved = algo / (k_med * 1e-3) / 1e9
+    return {'workload': label, 'features': f, 'n_nodes': a.n_rows, 'nnz': a.nnz, 'steps': steps,
+            'ms_per_product': w_med, 'ms_min': w_min, 'value_gbps': algo / (w_med * 1e-3) / 1e9,
+            'gather_gbps': gathered / (w_med * 1e-3) / 1e9,
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'spmm_rows_kernel',
+                         'kernel_ms': k_med, 'kernel_ms_min': k_min, 'algorithmic_bytes': algo}}
+
+
+def pubmed_support(device):
+    """A_hat of the PubMed graph from the committed vectors of the reference's own preprocess_adj."""
+    from gcn_amd import sparse
+    fx = np.load(os.path.join(ROOT, 'tests', 'golden', 'pubmed_graph.npz'))
+    n = int(fx['n'])
+    ip, ix = fx['ai_indptr'].astype(np.int64), fx['ai_indices'].astype(np.int32)
+    v = fx['hat_values'].astype(np.float32)
+    a = sparse.DeviceCSR(n, n, torch.as_tensor(ip).to(device), torch.as_tensor(ix).to(device),
+                         torch.as_tensor(v).to(device))
+    return a, (ip, ix, v)
+
+
+def smoothing_point(device, k=64, f=500, replays=20, with_cpu=True):
+    """A_hat^k X on PubMed (X seeded, 19,717 x 500), the k products recorded as ONE HIP graph and replayed:
+    microseconds per step = replay time / k.  Beside it the same step of the CPU oracle on one core."""
+    from gcn_amd import smoothing, sparse
+    a, (ip, ix, v) = pubmed_support(device)
+    x = sparse.synthetic_dense(a.n_rows, f, seed=7)
+    run = smoothing.GraphedPropagation(a, f, k)
+    for _ in range(3):
+        run(x)
+    torch.cuda.synchronize()
+    us = []
+    for _ in range(replays):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run.graph.replay()
+        e1.record()
+        e1.synchronize()
+        us.append(e0.elapsed_time(e1) * 1e3 / k)
+    med, low = _median_min(us)
+    algo = bytes_min(a.n_rows, a.n_cols, a.nnz, f)
+    achieved = algo / (med * 1e-6) / 1e9
+    out = {'workload': 'A_hat^k X on PubMed (A_hat from the reference vectors, X synthetic 19717 x %d), k = %d as one HIP graph'
+                       % (f, k), 'k': k, 'features': f, 'n_nodes': a.n_rows, 'nnz': a.nnz, 'replays': replays,
+           'us_per_step': med, 'us_per_step_min': low,
+           'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                        'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'spmm_rows_kernel',
+                        'kernel_ms': med * 1e-3, 'algorithmic_bytes': algo,
+                        'note': 'operand and result (79 MB) stay in the 256 MiB Infinity Cache between steps: '
+                                'this measures launch-to-launch latency and the gather path, not HBM'}}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import gcn_oracle as oracle
+        xh = x.cpu().numpy()
+        out_h = np.empty_like(xh)
+        oracle.spmm_csr(ip, ix, v, xh, threads=1, out=out_h)          # untimed first pass
+        t = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            oracle.spmm_csr(ip, ix, v, xh, threads=1, out=out_h)
+            t.append(time.perf_counter() - t0)
+        sec = float(np.median(t))
+        out['cpu_baseline'] = {'value': sec * 1e6, 'unit': 'us per step', 'cores': 1, 'kind': 'port',
+                               'sample': 'one step A_hat . X of the same size (median of 5), the serial loop of the '
+                                         'oracle', 'gbps': algo / sec / 1e9}
+    del run, x
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_planetoid_step(name, steps=8):
+    """One optimiser step (forward + backward + Adam, dropout 0.5: the region train.py:203-205 times) of
+    the CPU oracle -- the reference's arithmetic restated in numpy / C, one core -- on a Planetoid dataset
+    with the 20-labels-per-class split of the committed fixture."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import gcn_oracle as oracle
+    fx = np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'))
+    n = int(fx['n'])
+    ip, ix, v32, _ = oracle.triple_to_csr(fx['hat_indices'], fx['hat_values'], fx['hat_shape'])
+    feat = (fx['feat_indptr'].astype(np.int64), fx['feat_coords'][:, 1], fx['feat_values'].astype(np.float32))
+    f_in, classes = int(fx['feat_shape'][1]), int(fx['y_train'].shape[1])
+    rng = np.random.RandomState(123)
+    weights = [oracle.glorot((f_in, 16), rng), oracle.glorot((16, classes), rng)]
+    model = oracle.GcnOracle((ip, ix, v32), feat, n, weights)
+    adam = oracle.TfAdam(model.w, 0.02)
+    labels, mask = fx['y_train'], fx['train_mask']
+    ms = []
+    for step in range(steps + 1):
+        t0 = time.perf_counter()
+        logits = model.forward(dropout=0.5, seed=123, stream_ids=[2 * step, 2 * step + 1])
+        grads = model.backward(logits, labels, mask)
+        adam.step(model.w, grads)
+        if step:                                   # the first step is untimed
+            ms.append((time.perf_counter() - t0) * 1e3)
+    med, low = _median_min(ms)
+    return {'dataset': name, 'value': med, 'min': low, 'unit': 'ms per step', 'cores': 1, 'kind': 'port',
+            'sample': '%d optimiser steps of the oracle (numpy + the C loop of the sparse products), '
+                      'one thread; first step untimed' % steps}
+
+
+def other_configs(a24, scale, edge_factor, device, with_cpu):
+    """The other BASELINE configurations and the narrower widths of the headline graph, timed in this run."""
+    from gcn_amd import sparse
+    out = []
+    for f in (16, 64, 128):
+        out.append(product_point('A_hat.B, R-MAT scale %d edge factor %d, F=%d (the widths a GCN layer '
+                                 'propagates)' % (scale, edge_factor, f), a24, f))
+    # BASELINE config 4: R-MAT 2^22, average degree 32, 512 features
+    ip, ix, v = build_graph(22, 16)
+    a22 = sparse.DeviceCSR(1 << 22, 1 << 22, ip, ix, v)
+    out.append(product_point('BASELINE config 4: A_hat.B, R-MAT scale 22 edge factor 16, F=512', a22, 512))
+    del a22, ip, ix, v
+    torch.cuda.empty_cache()
+    # BASELINE config 3: k-step smoothing on PubMed
+    out.append(smoothing_point(device, with_cpu=with_cpu))
+    return out
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -276,7 +445,8 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
-    from gcn_amd import sparse, dist as gdist
+    from gcn_amd import _lib, sparse, dist as gdist
+    seen = ranks_seen(sharded, rank, dev)
 
     n = 1 << args.scale
     f = args.features
@@ -353,7 +523,9 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'A_hat.B, R-MAT scale %d edge factor %d (+I, sym-normalised), F=%d'
                                    % (args.scale, args.edge_factor, f),
-                       'n_nodes': n, 'nnz': nnz, 'features': f,
+                       'n_nodes': n, 'nnz': nnz, 'features': f, 'ranks_seen': seen,
+                       'library_build_hash': _lib.build_hash(),
+                       'library_matches_sources': _lib.build_hash() == _lib.source_hash(),
                        'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B pipelined over column ranges %s' % (op.ranges,))) if sharded else 'single GPU'},
             'pct_of_hbm_peak': 100.0 * value / (HBM_PEAK_GBPS * world),
             'gather_gbps': total_gather / (ms_per_step * 1e-3) / 1e9,
@@ -376,6 +548,20 @@ def main():
                     line['gcn_epoch'].append(planetoid_epoch_ms(name, hip_graph=recorded))
                 except Exception as exc:
                     line['gcn_epoch'].append({'dataset': name, 'error': '%s: %s' % (type(exc).__name__, exc)})
+            if not args.no_cpu_baseline:
+                # the same step of the CPU oracle on one core, beside the GPU's
+                line['gcn_epoch_cpu_baseline'] = []
+                for name in ('cora', 'citeseer'):
+                    try:
+                        line['gcn_epoch_cpu_baseline'].append(cpu_planetoid_step(name))
+                    except Exception as exc:
+                        line['gcn_epoch_cpu_baseline'].append({'dataset': name, 'error': '%s: %s' % (type(exc).__name__, exc)})
+        if not sharded and not args.no_configs:
+            try:
+                a.plan.set_timing(False)
+                line['configs'] = other_configs(a, args.scale, args.edge_factor, dev, not args.no_cpu_baseline)
+            except Exception as exc:
+                line['configs'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         rec = measured_traffic('spmm_rows_kernel', args.scale, args.edge_factor, f, world)
         if rec:
             # bytes behind the L2 per launch (Infinity-Cache hits included: an upper bound of the HBM bytes)
@@ -421,6 +607,8 @@ def main():
         if epoch is not None:
             line['gcn_epoch_rmat'] = epoch
         failed = failed or any('error' in leg for leg in line.get('gcn_epoch', []))
+        failed = failed or any('error' in leg for leg in line.get('gcn_epoch_cpu_baseline', []))
+        failed = failed or 'error' in line.get('configs', [])
         print(json.dumps(line), flush=True)
     if sharded:
         torch.distributed.barrier()
