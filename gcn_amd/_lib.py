@@ -48,6 +48,8 @@ SIGNATURES = {
     'gcn_csr_transpose': [_i64, _i64, _i64, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'gcn_degree_order_bound': [_i64, _psz],
     'gcn_degree_order': [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
+    'gcn_hub_order_bound': [_i64, _psz],
+    'gcn_hub_order': [_i64, _vp, _i64, _vp, _vp, _vp, _sz, _vp],
     'gcn_csr_relabel_bound': [_i64, _i64, _int, _psz],
     'gcn_csr_relabel': [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'gcn_check_indices': [_i64, _vp, _i64, _vp],

@@ -28,6 +28,7 @@ static void size_queries() {
         EXPECT(gcn_csr_transpose_bound(n, n, 5 * n, &bytes) == GCN_OK && bytes > 0);
         EXPECT(gcn_degree_order_bound(n, &bytes) == GCN_OK);
         EXPECT(gcn_csr_relabel_bound(n, 5 * n, 1, &bytes) == GCN_OK);
+        EXPECT(gcn_hub_order_bound(n, &bytes) == GCN_OK && bytes > 0);
         EXPECT(gcn_rmat_csr_rows_bound(7 * n, &bytes) == GCN_OK);
         EXPECT(gcn_gemm_tn_workspace_bytes(n, 256, 256, &bytes) == GCN_OK);
         EXPECT(gcn_gemm_tn_workspace_bytes(n, 7, 16, &bytes) == GCN_OK);
@@ -89,6 +90,7 @@ static void argument_validation() {
     EXPECT(gcn_csr_transpose(4, 4, 4, nullptr, nullptr, nullptr, 4, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                              nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_degree_order(4, nullptr, nullptr, nullptr, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_hub_order(4, nullptr, 1, nullptr, nullptr, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_csr_relabel(-1, 4, 4, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_check_indices(-1, nullptr, 4, nullptr) == GCN_ERR_BAD_ARG);

@@ -343,6 +343,35 @@ __global__ void order_from_keys_kernel(int64_t n, const uint64_t* __restrict__ s
     }
 }
 
+// Hub-first order.  sorted: the degree keys in ascending order (descending degree).  Position i < n_hubs: the
+// vertex is a hub and takes the new id i; every other vertex is flagged 1 in rest_flag (hubs 0).
+__global__ void hub_marks_kernel(int64_t n, int64_t n_hubs, const uint64_t* __restrict__ sorted,
+                                 int32_t* __restrict__ new_id, int64_t* __restrict__ rest_flag) {
+    GCN_GRID_STRIDE(i, n) {
+        const uint32_t v = (uint32_t)sorted[i];
+        if (i < n_hubs) {
+            new_id[v] = (int32_t)i;
+            rest_flag[v] = 0;
+        } else {
+            rest_flag[v] = 1;
+        }
+    }
+}
+
+// rest_rank: the exclusive scan of rest_flag = how many non-hub vertices precede v in the old order
+__global__ void hub_finish_kernel(int64_t n, int64_t n_hubs, const int64_t* __restrict__ rest_flag,
+                                  const int64_t* __restrict__ rest_rank, int32_t* __restrict__ new_id,
+                                  int32_t* __restrict__ old_id) {
+    GCN_GRID_STRIDE(v, n) {
+        int32_t id = new_id[v];
+        if (rest_flag[v]) {
+            id = (int32_t)(n_hubs + rest_rank[v]);
+            new_id[v] = id;
+        }
+        if (old_id) old_id[id] = (int32_t)v;
+    }
+}
+
 __global__ void relabel_keys_kernel(int64_t n_rows, int64_t nnz, const int64_t* __restrict__ indptr,
                                     const int32_t* __restrict__ indices, const int32_t* __restrict__ new_row,
                                     const int32_t* __restrict__ new_col, const double* __restrict__ vals,
@@ -719,6 +748,44 @@ int gcn_degree_order(int64_t n_rows, const int64_t* indptr, int32_t* new_id_out,
     size_t tb = s.prim_bytes;
     GCN_HIP_TRY(rocprim::radix_sort_keys(s.prim, tb, kd, (size_t)n_rows, 0u, 64u, st));
     order_from_keys_kernel<<<grid_for(n_rows), kBlock, 0, st>>>(n_rows, kd.current(), new_id_out, old_id_out);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_hub_order_bound(int64_t n_rows, size_t* workspace_bytes) {
+    if (n_rows < 0 || !workspace_bytes) return fail(GCN_ERR_BAD_ARG, "bad argument");
+    // the sort's scratch (its `pos` segment holds the flags) and one more segment for their scan
+    *workspace_bytes = sort_scratch_bytes(n_rows, false) + align_up((size_t)(n_rows > 0 ? n_rows : 1) * 8, 256);
+    return GCN_OK;
+}
+
+int gcn_hub_order(int64_t n_rows, const int64_t* indptr, int64_t n_hubs, int32_t* new_id_out, int32_t* old_id_out,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_rows < 0 || n_rows > INT32_MAX || n_hubs < 0 || !indptr || !new_id_out)
+        return fail(GCN_ERR_BAD_ARG, "bad argument");
+    if (n_rows == 0) return GCN_OK;
+    if (n_hubs > n_rows) n_hubs = n_rows;
+    hipStream_t st = (hipStream_t)stream;
+    size_t need = 0;
+    gcn_hub_order_bound(n_rows, &need);
+    if (!workspace || workspace_bytes < need)
+        return fail(GCN_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    SortScratch s;
+    const size_t sort_bytes = sort_scratch_bytes(n_rows, false);
+    int rc = carve_scratch(workspace, sort_bytes, n_rows, false, &s);
+    if (rc != GCN_OK) return rc;
+    int64_t* rest_rank = (int64_t*)((char*)workspace + sort_bytes);
+    degree_keys_kernel<<<grid_for(n_rows), kBlock, 0, st>>>(n_rows, indptr, s.keys_a);
+    GCN_LAUNCH_CHECK();
+    rocprim::double_buffer<uint64_t> kd(s.keys_a, s.keys_b);
+    size_t tb = s.prim_bytes;
+    GCN_HIP_TRY(rocprim::radix_sort_keys(s.prim, tb, kd, (size_t)n_rows, 0u, 64u, st));
+    hub_marks_kernel<<<grid_for(n_rows), kBlock, 0, st>>>(n_rows, n_hubs, kd.current(), new_id_out, s.pos);
+    GCN_LAUNCH_CHECK();
+    tb = s.prim_bytes;
+    GCN_HIP_TRY(rocprim::exclusive_scan(s.prim, tb, s.pos, rest_rank, (int64_t)0, (size_t)n_rows,
+                                        rocprim::plus<int64_t>(), st));
+    hub_finish_kernel<<<grid_for(n_rows), kBlock, 0, st>>>(n_rows, n_hubs, s.pos, rest_rank, new_id_out, old_id_out);
     GCN_LAUNCH_CHECK();
     return GCN_OK;
 }

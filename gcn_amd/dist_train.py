@@ -104,7 +104,22 @@ class ShardedGCN(object):
     backward product of that layer (see _AggregatedFirstLayerFn)."""
 
     def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
-                 seed=0, group=None, chunks=4, aggregate_first=None, receptive_field=True, labelled_logits_only=True):
+                 seed=0, group=None, chunks=4, aggregate_first=None, receptive_field=True, labelled_logits_only=True,
+                 reorder=None):
+        """``reorder`` ('degree', 'hubs' or ('hubs', K); one rank only): the model works on the graph with its
+        vertices relabelled once (utils.vertex_order); features, labels and masks given in the dataset's order
+        are permuted on their way in (once per tensor object) and ``forward`` returns its rows in the dataset's
+        order.  Dropout decisions are then drawn by the new row numbers."""
+        self._order = None
+        if reorder is not None:
+            if shard.world != 1:
+                raise ValueError('reorder relabels the whole graph: relabel before sharding (one rank only here)')
+            from .utils import relabelled_csr, vertex_order
+            new_id, old_id = vertex_order(shard.local.indptr, reorder)
+            shard = type(shard)(shard.n_rows_global, shard.n_cols, shard.row_begin, shard.row_end,
+                                relabelled_csr(shard.local, new_id), shard.rank, shard.world)
+            self._order = (new_id.to(torch.int64), old_id.to(torch.int64))
+            self._moved = {}
         self.shard, self.group = shard, group
         # ranges of feature columns an exchange is pipelined over: a count, or a tuple of width shares
         self.chunks = chunks if shard.world > 1 else 1
@@ -215,10 +230,26 @@ class ShardedGCN(object):
         p = _GatedGemmFn.apply(h, w1, keep) if drop else _GemmFn.apply(h, w1)
         return _HaloSpmmFn.apply(plans['logits'], p, False, self.chunks, True, None, plans['back'])
 
+    def _in_model_order(self, t):
+        """A per-node tensor given in the dataset's order, in the order the model works in."""
+        if self._order is None or t is None:
+            return t
+        hit = self._moved.get(id(t))
+        if hit is None or hit[0] is not t:
+            hit = (t, t[self._order[1]].contiguous())
+            self._moved[id(t)] = hit
+        return hit[1]
+
     def forward(self, x_local, train, logit_plans=None):
         """Dropout on every layer's input (gcn/models.py:60): a pass over the features for the first
         layer; for the others it is applied in the store of the product that makes the input, and its
-        backward (with the ReLU's) in the store of the product that makes the input's gradient."""
+        backward (with the ReLU's) in the store of the product that makes the input's gradient.
+        Rows in, rows out: the dataset's order."""
+        if self._order is not None:
+            return self._forward(self._in_model_order(x_local), train, logit_plans)[self._order[0]]
+        return self._forward(x_local, train, logit_plans)
+
+    def _forward(self, x_local, train, logit_plans=None):
         keep = 1.0 - self.dropout if train else 1.0
         drop = keep < 1.0
         h = x_local
@@ -265,6 +296,7 @@ class ShardedGCN(object):
         when the step runs on their receptive field; the weight gradients and the loss are summed over the
         ranks in one all-reduce; Adam and the weight-decay term run in one kernel per variable."""
         self.step_count += 1
+        x_local, labels_local, mask_local = (self._in_model_order(t) for t in (x_local, labels_local, mask_local))
         mask_mean = self._local_mask_mean(mask_local)
         with torch.enable_grad():
             if self.receptive_field and self.aggregate_first and len(self.weights) == 2:
@@ -287,8 +319,8 @@ class ShardedGCN(object):
                 else:                                                     # a rank without labelled nodes
                     dlogits, local_loss = torch.zeros_like(logits), torch.zeros(1, device=logits.device)
             else:
-                logits = self.forward(x_local, train=True,
-                                      logit_plans=self._logit_plans(mask_local) if self.labelled_logits_only else None)
+                logits = self._forward(x_local, train=True,
+                                       logit_plans=self._logit_plans(mask_local) if self.labelled_logits_only else None)
                 stats, dlogits = sparse.softmax_xent(logits.detach(), labels_local, mask_local, mask_mean)
                 local_loss = stats[:, 0].mean().reshape(1)
             grads = torch.autograd.grad(logits, self.weights, grad_outputs=dlogits)

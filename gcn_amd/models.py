@@ -72,6 +72,7 @@ class GCN_MLP(object):
         self.optimizer = None
         self._run_counter = 0
         self._device_cache = {}
+        self._new_id = None
         # train steps recorded as HIP graphs (one per distinct feed), replayed with a single launch:
         # on the citation graphs a step is ~30 kernels of a few microseconds each, bound by launch rate
         self.use_hip_graph = bool(model_config.get('hip_graph', False))
@@ -144,6 +145,43 @@ class GCN_MLP(object):
             if not isinstance(ph, graph.Placeholder):
                 raise TypeError('feed_dict keys must be placeholders')
             ph.value = self._to_device(ph, val)
+        self._bind_vertex_order(feed_dict)
+
+    def _bind_vertex_order(self, feed_dict):
+        """A support made with ``preprocess_adj(reorder=...)`` is the matrix of the relabelled graph: the
+        features, labels and mask fed beside it (in the dataset's order) are permuted to that order once per
+        fed object, and ``_evaluate`` puts the outputs back (``self._new_id``; None without a reorder)."""
+        self._new_id = None
+        orders = [(getattr(v, 'new_id', None), getattr(v, 'old_id', None)) for v in feed_dict.values()]
+        orders = [o for o in orders if o[0] is not None]
+        if not orders:
+            return
+        supports = self.placeholders['support']
+        if len(orders) != len(supports) or any(o[0] is not orders[0][0] and not torch.equal(o[0], orders[0][0])
+                                               for o in orders):
+            raise ValueError('every support of a model must carry the same vertex order')
+        new_id, old_id = orders[0]
+        self._new_id = new_id.to(torch.int64)
+        old = old_id.to(torch.int64)
+        for name in ('features', 'labels', 'labels_mask'):
+            ph = self.placeholders[name]
+            val = ph.value
+            if val is None:
+                continue
+            hit = self._device_cache.get(('reordered', id(val)))
+            if hit is None or hit[0] is not val:
+                if isinstance(val, sparse.DeviceCSR):
+                    moved = sparse.permute_rows(val, old_id)
+                    moved.perm = None        # sparse dropout draws by entry position in the permuted matrix
+                else:
+                    moved = val[old].contiguous()
+                hit = (val, moved)
+                self._device_cache[('reordered', id(val))] = hit
+            ph.value = hit[1]
+
+    def _dataset_order(self, rows):
+        """Rows of a per-node result in the dataset's order (undoes the support's vertex order)."""
+        return rows if self._new_id is None else rows[self._new_id]
 
     def _to_device(self, ph, val):
         if ph.sparse:
@@ -296,9 +334,9 @@ class GCN_MLP(object):
             if 'accuracy' in keys:
                 out['accuracy'] = np.float32(accuracy)
         if 'outputs' in keys:
-            out['outputs'] = graph.to_numpy(rec['outputs'])
+            out['outputs'] = graph.to_numpy(self._dataset_order(rec['outputs']))
         if 'prediction' in keys:
-            out['prediction'] = graph.to_numpy(rec['prediction'])
+            out['prediction'] = graph.to_numpy(self._dataset_order(rec['prediction']))
         return out
 
     def _evaluate(self, keys, feed_dict):
@@ -330,9 +368,9 @@ class GCN_MLP(object):
                 out['opt_op'] = None
         with torch.no_grad():
             if 'outputs' in keys:
-                out['outputs'] = graph.to_numpy(outputs)
+                out['outputs'] = graph.to_numpy(self._dataset_order(outputs))
             if 'prediction' in keys:
-                out['prediction'] = graph.to_numpy(torch.softmax(outputs, dim=1))      # models.py:89-90
+                out['prediction'] = graph.to_numpy(self._dataset_order(torch.softmax(outputs, dim=1)))   # models.py:89-90
             if 'loss' in keys or 'accuracy' in keys:
                 loss, accuracy = summary.tolist()                                               # one read-back for both
                 if 'loss' in keys:

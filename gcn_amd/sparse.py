@@ -271,6 +271,33 @@ def degree_order(indptr):
     return new_id, old_id
 
 
+def hub_order(indptr, n_hubs):
+    """Hub-first vertex order: the ``n_hubs`` vertices of highest degree first (in degree order), every other
+    vertex after them in its old order.  ``(new_id, old_id)`` as for ``degree_order``."""
+    _require_cuda(indptr)
+    n = indptr.numel() - 1
+    ws_bytes = ctypes.c_size_t()
+    _lib.call('gcn_hub_order_bound', n, ctypes.byref(ws_bytes))
+    ws = _workspace(ws_bytes.value, indptr.device)
+    new_id = torch.empty(n, dtype=torch.int32, device=indptr.device)
+    old_id = torch.empty(n, dtype=torch.int32, device=indptr.device)
+    _lib.call('gcn_hub_order', n, _p(indptr), int(n_hubs), _p(new_id), _p(old_id), _p(ws), ws.numel(), _stream())
+    return new_id, old_id
+
+
+def permute_rows(a, old_id):
+    """The CSR matrix whose row i is row ``old_id[i]`` of ``a``, the entries of every row in their old order
+    (the accumulation order of a product does not change); ``.perm`` gives every entry's position in the
+    matrix ``a`` came from, so that a fused sparse dropout draws the decisions of the unpermuted matrix."""
+    old = old_id.to(torch.int64)
+    lens = (a.indptr[1:] - a.indptr[:-1])[old]
+    indptr = torch.zeros(a.n_rows + 1, dtype=torch.int64, device=a.device)
+    torch.cumsum(lens, 0, out=indptr[1:])
+    src = torch.repeat_interleave(a.indptr[:-1][old] - indptr[:-1], lens) + torch.arange(a.nnz, device=a.device)
+    perm = src if a.perm is None else a.perm[src]
+    return DeviceCSR(a.n_rows, a.n_cols, indptr, a.indices[src].contiguous(), a.values[src].contiguous(), perm=perm)
+
+
 def csr_relabel(n_rows, n_cols, indptr, indices, vals=None, new_row=None, new_col=None):
     """(indptr, indices, vals) of the matrix with entry (r, c) moved to (new_row[r], new_col[c]);
     ``vals`` float64 or None (structure only)."""

@@ -75,11 +75,41 @@ def normalize_adj(adj, type='sym', device='cuda'):
     return sp.csr_matrix((w64.cpu().numpy(), cols, indptr.cpu().numpy()), shape=(n, n))
 
 
-def preprocess_adj(adj, type='sym', loop=True, device='cuda'):
+HUB_COUNT = 65536          # vertices moved to the front by reorder='hubs'
+
+
+def vertex_order(indptr, reorder):
+    """(new_id, old_id) of a vertex order named by ``reorder``: 'degree' (descending degree), 'hubs' (the
+    HUB_COUNT vertices of highest degree first, the others in their old order) or ('hubs', K)."""
+    if reorder == 'degree':
+        return sparse.degree_order(indptr)
+    if reorder == 'hubs':
+        return sparse.hub_order(indptr, HUB_COUNT)
+    if isinstance(reorder, (tuple, list)) and len(reorder) == 2 and reorder[0] == 'hubs':
+        return sparse.hub_order(indptr, int(reorder[1]))
+    raise ValueError("reorder must be None, 'degree', 'hubs' or ('hubs', K), not %r" % (reorder,))
+
+
+def relabelled_csr(csr, new_id):
+    """P . A . P^T of a square float32 DeviceCSR for the labels ``new_id``: columns ascend inside every row
+    of the result, values move with their entries."""
+    n = csr.n_rows
+    ip, ix, v = sparse.csr_relabel(n, n, csr.indptr, csr.indices, csr.values.double(), new_id, new_id)
+    return sparse.DeviceCSR(n, n, ip, ix.contiguous(), v.to(torch.float32))
+
+
+def preprocess_adj(adj, type='sym', loop=True, device='cuda', reorder=None):
     """Preprocessing of the adjacency matrix for the GCN model and conversion to the triple
     representation (gcn/utils.py:318-323): ``adj + I`` (ADDS 1 to the diagonal), degree^-1/2
     scaling in float64, triple in the element order of the reference (column-major for 'sym').
-    The returned triple's ``.csr`` is the float32 device CSR of the same matrix."""
+    The returned triple's ``.csr`` is the float32 device CSR of the same matrix.
+
+    ``reorder`` ('degree', 'hubs' or ('hubs', K); the reference has no such step): the device CSR is the
+    matrix of the graph with its vertices relabelled once, by an integer kernel, so that the rows of the dense
+    operand that most entries read sit next to each other; the triple itself stays in the dataset's order, and
+    ``.new_id`` / ``.old_id`` (int32 device tensors) carry the permutation.  A model fed this support
+    permutes features, labels and masks in and its outputs back (GCN_MLP does), so callers see the dataset's
+    order throughout; products then add a row's terms in the order of the NEW column numbers."""
     if type not in ('sym', 'rw'):
         raise ValueError('Invalid normalisation type: ' + str(type))
     n, indptr, indices, w64, w32 = _normalize_on_device(adj, type, loop, device)
@@ -95,6 +125,10 @@ def preprocess_adj(adj, type='sym', loop=True, device='cuda'):
         coords = torch.stack([rows.to(torch.int32), indices], dim=1)
         csr = sparse.DeviceCSR(n, n, indptr, indices, w32)
     out = SupportValue(coords.cpu().numpy(), w64.cpu().numpy(), np.array([n, n], dtype=np.int64))
+    out.new_id = out.old_id = None
+    if reorder is not None:
+        out.new_id, out.old_id = vertex_order(csr.indptr, reorder)
+        csr = relabelled_csr(csr, out.new_id)
     out.csr = csr
     return out
 

@@ -139,6 +139,19 @@ def degree_order(indptr):
     return new_id, old_id
 
 
+def hub_order(indptr, n_hubs):
+    """Hub-first order: the n_hubs vertices of highest degree first (descending degree, ties by ascending id),
+    every other vertex after them in its old order.  Returns (new_id, old_id) like degree_order."""
+    by_degree, sorted_ids = degree_order(indptr)
+    n = by_degree.size
+    n_hubs = min(int(n_hubs), n)
+    is_hub = by_degree < n_hubs
+    old_id = np.concatenate([sorted_ids[:n_hubs], np.nonzero(~is_hub)[0]]).astype(np.int32)
+    new_id = np.empty(n, dtype=np.int32)
+    new_id[old_id] = np.arange(n, dtype=np.int32)
+    return new_id, old_id
+
+
 def csr_relabel(n_rows, indptr, indices, vals, new_row, new_col):
     """CSR of the matrix with entry (r, c) moved to (new_row[r], new_col[c]), columns ascending."""
     indptr = np.asarray(indptr, dtype=np.int64)

@@ -371,3 +371,39 @@ def test_receptive_field_step_equals_the_full_step():
     for a, b in zip(w0, w1):        # Adam divides by sqrt(v): entries whose gradient is nearly zero amplify rounding
         d, top = (a - b).abs(), float(a.abs().max())
         assert float((d <= 1e-5 * top).float().mean()) >= 0.999 and float(d.max()) <= 1e-3 * top
+
+
+@pytest.mark.parametrize('reorder', ['degree', ('hubs', 64)])
+@pytest.mark.parametrize('form', [dict(aggregate_first=False, receptive_field=False), dict()])
+def test_sharded_model_on_a_relabelled_graph_follows_the_plain_one(reorder, form):
+    """ShardedGCN(reorder=...): the graph is relabelled once, inputs are permuted on their way in and the
+    forward's rows come back in the dataset's order.  With dropout off it is the same model up to the order
+    of the additions: same forward, same loss trajectory and weights over 4 Adam steps (1e-5)."""
+    from gcn_amd import dist as gdist, sparse
+    from gcn_amd.dist_train import ShardedGCN
+    scale, f_in, hidden, classes = 12, 32, 16, 5
+    n = 1 << scale
+    indptr, indices = sparse.rmat_csr(scale, 8, seed=3, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, 1)
+    x = sparse.synthetic_dense(n, f_in, seed=7)
+    gen = torch.Generator().manual_seed(5)
+    labels = torch.nn.functional.one_hot(torch.randint(0, classes, (n,), generator=gen), classes).to(torch.int32).cuda()
+    mask = (torch.rand(n, generator=gen) < 0.2).to(torch.int32).cuda()
+    kw = dict(learning_rate=0.02, weight_decay=5e-4, dropout=0.0, seed=9, **form)
+    plain = ShardedGCN(shard, f_in, [hidden], classes, **kw)
+    moved = ShardedGCN(shard, f_in, [hidden], classes, reorder=reorder, **kw)
+    assert not torch.equal(moved.shard.local.indices, shard.local.indices)
+    with torch.no_grad():
+        a, b = plain.forward(x, train=False), moved.forward(x, train=False)
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    for step in range(4):
+        la, lb = float(plain.train_step(x, labels, mask)), float(moved.train_step(x, labels, mask))
+        assert abs(la - lb) <= 1e-5 * abs(la), (step, la, lb)
+    for wa, wb in zip(plain.weights, moved.weights):
+        dw = (wa.detach() - wb.detach()).abs()
+        assert float((dw <= 1e-5 * wa.detach().abs().max()).float().mean()) >= 0.999 and float(dw.max()) <= 1e-3 * float(wa.detach().abs().max())
+    with pytest.raises(ValueError, match='one rank'):
+        two = gdist.RowShardedCSR(n, n, 0, n // 2, shard.local, 0, 2)
+        ShardedGCN(two, f_in, [hidden], classes, reorder='degree')

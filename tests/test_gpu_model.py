@@ -322,3 +322,79 @@ def test_pubmed_two_layer_logits_at_fixed_weights(oracle, dense_input):
         + float(oracle.GcnOracle.masked_softmax_cross_entropy(ref64, labels, mask))      # gcn/models.py:92-99
     assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
     assert abs(float(acc) - float(oracle.GcnOracle.masked_accuracy(ref64, labels, mask))) <= 1e-6
+
+
+@pytest.mark.parametrize('name', ['cora', 'citeseer'])
+@pytest.mark.parametrize('reorder', ['degree', 'hubs', ('hubs', 100)])
+def test_model_on_a_relabelled_support_equals_the_oracle_on_the_relabelled_graph(name, reorder, oracle):
+    """preprocess_adj(reorder=...): the model multiplies with the matrix of the relabelled graph and permutes
+    features, labels and mask in and its outputs back.  The oracle, run on the relabelled matrix with the
+    permuted inputs, must agree: first-layer activations (sparse products only) bit for bit, logits, loss
+    and three training steps with dropout (decisions drawn in the relabelled order on both sides) to the
+    float32 tolerance -- and the triple the caller sees stays the reference's."""
+    import scipy.sparse as sp
+    import torch
+    from gcn_amd import graph as tf
+    from gcn_amd.models import GCN_MLP
+    from gcn_amd.utils import SupportValue, construct_feed_dict, preprocess_adj
+    fx = load_golden(name)
+    n = int(fx['n'])
+    adj = sp.csr_matrix((np.ones(fx['adj_row'].size), (fx['adj_row'], fx['adj_col'])), shape=(n, n))
+    support = [preprocess_adj(adj, reorder=reorder)]
+    s = support[0]
+    assert np.array_equal(s.indices, fx['hat_indices']) and np.array_equal(s.dense_shape, fx['hat_shape'])
+    new_id, old_id = s.new_id.cpu().numpy(), s.old_id.cpu().numpy()
+    ip0, ix0, v0, _ = oracle.triple_to_csr(fx['hat_indices'], fx['hat_values'], fx['hat_shape'])
+    want = oracle.degree_order(ip0) if reorder == 'degree' else oracle.hub_order(ip0, 65536 if reorder == 'hubs' else 100)
+    assert np.array_equal(new_id, want[0]) and np.array_equal(old_id, want[1])
+    rip, rix, rv = oracle.csr_relabel(n, ip0, ix0, v0.astype(np.float64), new_id, new_id)
+    assert np.array_equal(s.csr.indptr.cpu().numpy(), rip) and np.array_equal(s.csr.indices.cpu().numpy(), rix)
+    assert np.array_equal(s.csr.values.cpu().numpy(), rv.astype(np.float32))
+    # the model, fed in the dataset's order
+    features = SupportValue(fx['feat_coords'], fx['feat_values'], fx['feat_shape'])
+    y_train, train_mask = fx['y_train'].astype(np.float64), fx['train_mask']
+    tf.set_random_seed(9)
+    placeholders = {
+        'support': [tf.sparse_placeholder(tf.float32, name='support0')],
+        'features': tf.sparse_placeholder(tf.float32, name='features'),
+        'labels': tf.placeholder(tf.int32, name='labels', shape=(None, y_train.shape[1])),
+        'labels_mask': tf.placeholder(tf.int32, name='labels_mask'),
+        'dropout': tf.placeholder_with_default(0., name='dropout', shape=()),
+        'num_features_nonzero': tf.placeholder(tf.int32, name='num_features_nonzero'),
+    }
+    cfg = {'name': 'gcn', 'connection': ['c', 'c'], 'layer_size': [16], 'conv': 'gcn', 'learning_rate': 0.02,
+           'weight_decay': 5e-4, 'Model': 'GCN', 'dropout': 0.5}
+    model = GCN_MLP(cfg, placeholders, input_dim=int(fx['feat_shape'][1]))
+    feed = construct_feed_dict(features, support, y_train, train_mask, placeholders)
+    # the oracle on the relabelled problem: X, labels and mask with their rows in the new order
+    fip = fx['feat_indptr'].astype(np.int64)
+    lens = np.diff(fip)[old_id]
+    pip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    src = np.repeat(fip[:-1][old_id] - pip[:-1], lens) + np.arange(pip[-1])
+    feat = (pip, fx['feat_coords'][:, 1][src], fx['feat_values'].astype(np.float32)[src])
+    weights = [w.detach().cpu().numpy().copy() for w in model._trainable()]
+    ref = oracle.GcnOracle((rip, rix, rv.astype(np.float32)), feat, n, weights)
+    labels_r, mask_r = fx['y_train'][old_id], fx['train_mask'][old_id]
+    sess = tf.Session()
+    outputs, loss = sess.run([model.outputs, model.loss], feed_dict=feed)
+    logits = ref.forward()
+    assert np.array_equal(model.activations[1].cpu().numpy(), np.maximum(ref.cache['z'][0], 0))
+    assert _close(outputs, logits[new_id])                                # outputs come back in the dataset's order
+    assert abs(float(loss) - float(ref.loss(logits, labels_r, mask_r))) <= 1e-5 * abs(float(loss))
+    # and they are the unordered model's outputs up to the order of the additions
+    plain = [preprocess_adj(adj)]
+    feed_plain = construct_feed_dict(features, plain, y_train, train_mask, placeholders)
+    assert _close(sess.run(model.outputs, feed_dict=feed_plain), outputs, 1e-5)
+    # three optimiser steps with dropout
+    feed = dict(feed)
+    feed[placeholders['dropout']] = 0.5
+    adam = oracle.TfAdam(ref.w, 0.02)
+    for _ in range(3):
+        sess.run(model.opt_op, feed_dict=feed)
+        run = model._run_counter
+        lg = ref.forward(dropout=0.5, seed=9, stream_ids=[run * 64, run * 64 + 1])
+        adam.step(ref.w, ref.backward(lg, labels_r, mask_r))
+    for p, rw in zip(model._trainable(), ref.w):
+        d = np.abs(p.detach().cpu().numpy().astype(np.float64) - rw)
+        scale = np.abs(rw).max()
+        assert (d <= REL_TOL * scale).mean() >= 0.999 and d.max() <= 1e-3 * scale

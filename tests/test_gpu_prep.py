@@ -311,3 +311,22 @@ def test_rmat_natural_order_and_hot_column_hint(oracle):
             a.plan.set_hot_columns(hot)
             assert torch.equal(sparse.spmm(a, b), plain)
         a.plan.set_hot_columns(0)
+
+
+@pytest.mark.parametrize('n_hubs', [0, 1, 37, 4096, 1 << 20])
+def test_hub_first_order_against_the_oracle(oracle, n_hubs):
+    """gcn_hub_order: the n_hubs vertices of highest degree first, the others in their old order."""
+    import torch
+    from gcn_amd import sparse
+    ip, ix = sparse.rmat_csr(14, 16, seed=42, self_loops=True)
+    new_id, old_id = sparse.hub_order(ip, n_hubs)
+    want_new, want_old = oracle.hub_order(ip.cpu().numpy(), n_hubs)
+    assert np.array_equal(new_id.cpu().numpy(), want_new) and np.array_equal(old_id.cpu().numpy(), want_old)
+    n = ip.numel() - 1
+    assert torch.equal(torch.sort(new_id.to(torch.int64)).values, torch.arange(n, device='cuda'))
+    k = min(n_hubs, n)
+    rest = old_id[k:].to(torch.int64)
+    assert bool((rest[1:] > rest[:-1]).all())                       # the others keep their order
+    deg = (ip[1:] - ip[:-1])
+    if 0 < k < n:
+        assert int(deg[old_id[:k].to(torch.int64)].min()) >= int(deg[rest].max())

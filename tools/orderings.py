@@ -33,6 +33,17 @@ def build(scale, order):
     n = 1 << scale
     indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True, scramble=(order != 'natural'))
     new_id = None
+    if order.startswith('hubs'):
+        # the K vertices of highest degree first (in degree order), every other vertex after them in its old order
+        k = int(order[4:])
+        by_degree, _ = sparse.degree_order(indptr)                     # position of every vertex in degree order
+        is_hub = by_degree < k
+        rest_rank = torch.cumsum((~is_hub).to(torch.int32), 0, dtype=torch.int32) - 1
+        new_id = torch.where(is_hub, by_degree, rest_rank + k).to(torch.int32).contiguous()
+        indptr, indices, _ = sparse.csr_relabel(n, n, indptr, indices, None, new_id, new_id)
+        indices = indices.clone()
+        del by_degree, is_hub, rest_rank
+        torch.cuda.empty_cache()
     if order == 'degree':
         new_id, old_id = sparse.degree_order(indptr)
         indptr, indices, _ = sparse.csr_relabel(n, n, indptr, indices, None, new_id, new_id)
