@@ -82,6 +82,9 @@ SIGNATURES = {
     'gcn_row_normalize': [_i64, _i64, _vp, _vp, _int, _vp, _vp],
     'gcn_dropout_f32': [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _f32, _u64, _u64, _vp, _u64, _vp],
     'gcn_gemm_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i64, _int, _vp],
+    'gcn_dropout_bits': [_i64, _i64, _f32, _u64, _u64, _vp, _u64, _i64, _vp, _i64, _vp],
+    'gcn_gemm_masked_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _int, _vp, _i64, _int, _vp],
+    'gcn_gemm_tn_masked_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _i64, _vp, _sz, _vp],
     'gcn_gemm_tn_workspace_bytes': [_i64, _i64, _i64, ctypes.POINTER(ctypes.c_size_t)],
     'gcn_gather_rows_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp],
     'gcn_comm_unique_id': [_vp],

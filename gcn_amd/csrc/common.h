@@ -42,13 +42,42 @@ __host__ __device__ __forceinline__ uint64_t sm64(uint64_t x) {
 __host__ __device__ __forceinline__ uint64_t stream_key(uint64_t seed, uint64_t stream_id) {
     return sm64(sm64(seed) ^ stream_id);
 }
-// 24 random bits -> u in [0,1), exactly representable in float32
-__device__ __forceinline__ float uniform24(uint64_t key, uint64_t idx) {
-    return (float)(uint32_t)(sm64(key ^ idx) >> 40) * 5.9604644775390625e-08f;  // 2^-24
+// Dropout decisions: one 64-bit hash serves FOUR consecutive decision ids -- h = sm64(key ^ (idx >> 2)), and
+// decision idx reads the 16-bit field (idx & 3) of h, most significant field first -- because the two 64-bit
+// multiplications of a hash are what a dropout costs (integer multiplies run at a quarter of the vector
+// rate): a kernel whose lane holds 4 consecutive ids hashes once for them.
+//   u = field * 2^-16 in [0,1), exactly representable in float32
+__host__ __device__ __forceinline__ uint64_t decision_hash(uint64_t key, uint64_t idx) { return sm64(key ^ (idx >> 2)); }
+__host__ __device__ __forceinline__ uint32_t decision_field(uint64_t h, uint64_t idx) {
+    return (uint32_t)(h >> (48 - 16 * (int)(idx & 3))) & 0xffffu;
+}
+__device__ __forceinline__ float uniform16(uint64_t key, uint64_t idx) {
+    return (float)decision_field(decision_hash(key, idx), idx) * 1.52587890625e-05f;  // 2^-16
 }
 // dropout predicate of gcn/layers.py:21-23: floor(keep_prob + u) == 1, evaluated in float32
 __device__ __forceinline__ bool keep_entry(uint64_t key, uint64_t idx, float keep_prob) {
-    return floorf(__fadd_rn(keep_prob, uniform24(key, idx))) >= 1.0f;
+    return floorf(__fadd_rn(keep_prob, uniform16(key, idx))) >= 1.0f;
+}
+// The same predicate as an integer comparison: field >= keep_threshold(keep_prob), the smallest field value
+// whose u passes (the float32 sum keep_prob + u is monotone in u, so the two forms agree on every field value;
+// 65536 when none passes).
+__host__ __device__ __forceinline__ bool passes_f32(float keep_prob, uint32_t field) {
+    const float sum = keep_prob + (float)field * 1.52587890625e-05f;   // one rounding: no contraction possible
+    return sum >= 1.0f;                                                // floor(sum) >= 1 for a non-negative sum
+}
+static inline uint32_t keep_threshold(float keep_prob) {
+    uint32_t lo = 0, hi = 65536;                // smallest t in [0, 65536] with passes(t); passes(65536) taken as true
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (passes_f32(keep_prob, mid))
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ bool keep_field(uint64_t h, uint64_t idx, uint32_t threshold) {
+    return decision_field(h, idx) >= threshold;
 }
 
 // Dropout applied to the OUTPUT of a product -- sparse x dense or dense x dense -- (the next layer's
@@ -57,7 +86,7 @@ __device__ __forceinline__ bool keep_entry(uint64_t key, uint64_t idx, float kee
 // `pitch` columns wide would draw, of which C may be a row block and a column range.
 struct OutDrop {
     uint64_t key;
-    float keep_prob;     // 1: off
+    float keep_prob;     // 1: off (the launchers fill `threshold` from it: out_drop_ready)
     int64_t index_offset;
     int64_t pitch;
     const uint64_t* stream_offset;  // device value added to stream_id when the kernel runs (HIP-graph replays); may be null
@@ -65,7 +94,12 @@ struct OutDrop {
     // dense products only, may be null: row r of C is row row_ids[r] of the matrix the decisions are drawn
     // for (C holds a subset of its rows)
     const int64_t* row_ids;
+    uint32_t threshold;  // keep_threshold(keep_prob)
 };
+static inline OutDrop out_drop_ready(OutDrop od) {
+    od.threshold = keep_threshold(od.keep_prob);
+    return od;
+}
 
 // Fixed bijection on [0, 2^bits): odd multiplications and xor-shifts, each invertible modulo 2^bits.
 // The R-MAT generator relabels vertices with it so that hub vertices are spread over the id range.

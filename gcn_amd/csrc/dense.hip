@@ -1,6 +1,7 @@
 // Dense pieces of the GCN layer: tf.nn.dropout (gcn/layers.py:185) and the feature transform
 // H.W (gcn/layers.py:32-33) on the float32 MFMA pipe of gfx950.
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 
 #include "common.h"
@@ -14,7 +15,7 @@ constexpr int kBlock = 256;
 // ------------------------------------------------------------------------------------------------
 __global__ void dropout_kernel(int64_t n_rows, int64_t f, const float* __restrict__ x, int64_t ldx,
                                const float* __restrict__ gate, int64_t ldg, float* __restrict__ y, int64_t ldy,
-                               float keep_prob, uint64_t key, uint64_t index_offset,
+                               float keep_prob, uint32_t threshold, uint64_t key, uint64_t index_offset,
                                const uint64_t* __restrict__ stream_offset, uint64_t seed, uint64_t stream_id) {
     if (stream_offset) key = stream_key(seed, stream_id + *stream_offset);  // per replay of a recorded launch
     const int64_t total = n_rows * f;
@@ -23,7 +24,8 @@ __global__ void dropout_kernel(int64_t n_rows, int64_t f, const float* __restric
         float v = x[r * ldx + c];
         // TF 1.x: div(x, keep_prob) * floor(keep_prob + uniform)
         v = __fdiv_rn(v, keep_prob);
-        v = keep_entry(key, index_offset + (uint64_t)i, keep_prob) ? v : 0.0f;
+        const uint64_t id = index_offset + (uint64_t)i;
+        v = keep_field(decision_hash(key, id), id, threshold) ? v : 0.0f;
         if (gate && !(gate[r * ldg + c] > 0.0f)) v = 0.0f;
         y[r * ldy + c] = v;
     }
@@ -34,9 +36,11 @@ __global__ void dropout_kernel(int64_t n_rows, int64_t f, const float* __restric
 // ReLU-gate pass of the backward).
 template <bool RNG>
 __global__ void dropout_vec_kernel(int64_t n_vec, const float4* __restrict__ x, const float4* __restrict__ gate,
-                                   float4* __restrict__ y, float keep_prob, uint64_t key, uint64_t index_offset,
-                                   const uint64_t* __restrict__ stream_offset, uint64_t seed, uint64_t stream_id) {
+                                   float4* __restrict__ y, float keep_prob, uint32_t threshold, uint64_t key,
+                                   uint64_t index_offset, const uint64_t* __restrict__ stream_offset, uint64_t seed,
+                                   uint64_t stream_id) {
     if (RNG && stream_offset) key = stream_key(seed, stream_id + *stream_offset);
+    const bool one_hash = (index_offset & 3) == 0;     // a vector's 4 ids then start at a multiple of 4: one hash
     // a block takes contiguous tiles of kDepth x 256 vectors (16 KB), kDepth independent 128-bit loads in
     // flight per thread; consecutive blocks take consecutive tiles, so the accesses in flight at any
     // time cover one contiguous stretch of memory (6.2 TB/s; a grid-stride loop over single vectors
@@ -61,10 +65,12 @@ __global__ void dropout_vec_kernel(int64_t n_vec, const float4* __restrict__ x, 
             float o[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
             if (RNG) {
                 const uint64_t id = index_offset + 4 * (uint64_t)i;
+                const uint64_t h4 = one_hash ? decision_hash(key, id) : 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    const uint64_t h = one_hash ? h4 : decision_hash(key, id + e);
                     o[e] = __fdiv_rn(o[e], keep_prob);
-                    o[e] = keep_entry(key, id + e, keep_prob) ? o[e] : 0.0f;
+                    o[e] = keep_field(h, id + e, threshold) ? o[e] : 0.0f;
                 }
             }
             if (gate) {
@@ -76,6 +82,57 @@ __global__ void dropout_vec_kernel(int64_t n_vec, const float4* __restrict__ x, 
             y[i] = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
+}
+
+// The decisions of tf.nn.dropout on a matrix [n_rows x f], one bit per element: bit c % 32 of word c / 32 of
+// row r is 1 iff element (r, c) is kept -- decision index_offset + r * pitch + c of the stream, the one
+// dropout_kernel draws.  One thread per word (32 hashes); columns past f give 0 bits.
+__global__ void dropout_bits_kernel(int64_t n_rows, int64_t f, int64_t words_per_row, uint32_t threshold, uint64_t key,
+                                    uint64_t index_offset, int64_t pitch, uint32_t* __restrict__ bits, int64_t ld_words,
+                                    const uint64_t* __restrict__ stream_offset, uint64_t seed, uint64_t stream_id) {
+    if (stream_offset) key = stream_key(seed, stream_id + *stream_offset);
+    const int64_t total = n_rows * words_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / words_per_row, w = i - r * words_per_row;
+        const int64_t c0 = w * 32;
+        const uint64_t id0 = index_offset + (uint64_t)(r * pitch + c0);
+        uint32_t word = 0;
+        if ((id0 & 3) == 0) {                 // the word's 32 ids are 8 whole groups of 4: 8 hashes
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint64_t h = decision_hash(key, id0 + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (keep_field(h, (uint64_t)e, threshold)) word |= 1u << (4 * q + e);
+            }
+            if (c0 + 32 > f) word &= (f - c0 >= 32) ? 0xffffffffu : ((1u << (int)(f - c0)) - 1u);
+        } else {
+#pragma unroll 8
+            for (int e = 0; e < 32; ++e) {
+                const uint64_t id = id0 + (uint64_t)e;
+                if (c0 + e < f && keep_field(decision_hash(key, id), id, threshold)) word |= 1u << e;
+            }
+        }
+        bits[r * ld_words + w] = word;
+    }
+}
+
+// A masked, scaled element of the left operand: tf.nn.dropout's `div(x, keep_prob) * floor(keep_prob + u)`
+// with the decision read from a mask bit.  A keep probability that is a power of two divides exactly as a
+// product with its inverse (one instruction instead of a correctly rounded division).
+struct InMask {
+    const uint32_t* bits;   // null: no input dropout
+    int64_t ld_words;
+    float keep_prob, inv_keep;
+    int exact;              // keep_prob is a power of two
+};
+__device__ __forceinline__ float masked_scaled(float x, uint32_t word, int bit, const InMask& im) {
+    const float q = im.exact ? x * im.inv_keep : __fdiv_rn(x, im.keep_prob);
+    return ((word >> bit) & 1u) ? q : 0.0f;
+}
+__device__ __forceinline__ float4 masked_scaled4(float4 v, uint32_t word, int shift, const InMask& im) {
+    return make_float4(masked_scaled(v.x, word, shift, im), masked_scaled(v.y, word, shift + 1, im),
+                       masked_scaled(v.z, word, shift + 2, im), masked_scaled(v.w, word, shift + 3, im));
 }
 
 // dst[i, :] = src[rows[i], :] for a column range of a row-major matrix: the send buffer of the
@@ -131,7 +188,7 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
                                                            float* __restrict__ c, int64_t ldc, int relu, int a_vec,
                                                            int b_vec, int64_t tiles_m, int64_t tiles_n,
                                                            const float* __restrict__ gate, int64_t ldg,
-                                                           float divisor, OutDrop od) {
+                                                           float divisor, OutDrop od, InMask im) {
     constexpr int kWavesN = (BN >= 64) ? 2 : 1;
     constexpr int kWavesM = 4 / kWavesN;
     constexpr int MT = kBM / (kWavesM * 32);
@@ -178,10 +235,20 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
 
     // loaders: A and B separately, so that a narrow output (n < BN: every tile is an edge tile in n) still
     // streams A -- nearly all of the bytes -- without a bounds test per element
+    // input dropout on A (im.bits): a float4 holds 4 consecutive k of one row, all inside one mask word
+    auto mask_a = [&](int i, int64_t gr, int64_t k0) {
+        if (im.bits) {
+            const int64_t kk = k0 + a_kq;
+            const uint32_t word = (gr < m && kk < k) ? im.bits[gr * im.ld_words + (kk >> 5)] : 0u;
+            ra[i] = masked_scaled4(ra[i], word, (int)(kk & 31), im);
+        }
+    };
     auto load_a_fast = [&](int64_t k0) {
 #pragma unroll
-        for (int i = 0; i < kAPer; ++i)
+        for (int i = 0; i < kAPer; ++i) {
             ra[i] = *reinterpret_cast<const float4*>(a + (m0 + a_r + kARows * i) * lda + k0 + a_kq);
+            mask_a(i, m0 + a_r + kARows * i, k0);
+        }
     };
     auto load_b_fast = [&](int64_t k0) {
 #pragma unroll
@@ -207,6 +274,7 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
                 for (int e = 0; e < 4; ++e) t[e] = (gr < m && k0 + a_kq + e < k) ? ap[e] : 0.0f;
                 ra[i] = make_float4(t[0], t[1], t[2], t[3]);
             }
+            mask_a(i, gr, k0);
         }
     };
     auto load_b_guarded = [&](int64_t k0) {
@@ -404,7 +472,7 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
                     for (int e = 0; e < 16; ++e) {
                         float v = acc[i][j][e];
                         if (relu) v = v > 0.0f ? v : 0.0f;
-                        cp[0] = keep_entry(key, id, od.keep_prob) ? __fdiv_rn(v, od.keep_prob) : 0.0f;
+                        cp[0] = keep_field(decision_hash(key, id), id, od.threshold) ? __fdiv_rn(v, od.keep_prob) : 0.0f;
                         const int step = ((e & 3) == 3) ? 5 : 1;
                         cp += step * ldc;
                         id += (uint64_t)(step * od.pitch);
@@ -425,7 +493,8 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
                         if (relu) v = v > 0.0f ? v : 0.0f;
                         const int64_t drawn_row = od.row_ids ? od.row_ids[gr] : gr;
                         const uint64_t id = (uint64_t)(od.index_offset + drawn_row * od.pitch + gc);
-                        c[gr * ldc + gc] = keep_entry(key, id, od.keep_prob) ? __fdiv_rn(v, od.keep_prob) : 0.0f;
+                        c[gr * ldc + gc] =
+                            keep_field(decision_hash(key, id), id, od.threshold) ? __fdiv_rn(v, od.keep_prob) : 0.0f;
                     }
                 }
             }
@@ -485,20 +554,34 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(int64_t m, int64_t
 //    passes as itself (tested on rows that hold NaN, both infinities and negative underflow).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-enum { kEpiPlain = 0, kEpiGate = 1 };
+enum { kEpiPlain = 0, kEpiGate = 1, kEpiDrop = 2 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_range_buffer(const void* base) {
     // raw buffer (stride 0), no range clamp below 4 GiB, 32-bit data format
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
 }
 
-template <bool TRANS_B, int EPI>
+// A_MASK: input dropout on A from mask bits (InMask), applied between the global load of a stage and its LDS
+// store: one more dword load per row and stage (the mask word of the stage's 32 k) and ~3 vector instructions per
+// element.  EPI == kEpiDrop: the store applies the NEXT layer's input dropout to the (optionally rectified)
+// output, one hash per element (OutDrop; row_ids optional).
+// the value lane `src` (0..3) of every quad holds, in all four lanes of the quad (a DPP quad_perm move)
+__device__ __forceinline__ uint32_t quad_read(uint32_t x, int src) {
+    switch (src) {
+        case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x00, 0xf, 0xf, true);
+        case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x55, 0xf, 0xf, true);
+        case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xaa, 0xf, 0xf, true);
+        default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xff, 0xf, 0xf, true);
+    }
+}
+
+template <bool TRANS_B, int EPI, bool A_MASK = false>
 __global__ __launch_bounds__(kBlock, 3) void gemm_panels_kernel(int tiles_m, int n_ktiles,
                                                                const float* __restrict__ a, int64_t lda,
                                                                const float* __restrict__ b, int64_t ldb,
                                                                float* __restrict__ c, int64_t ldc, int relu,
                                                                const float* __restrict__ gate, int64_t ldg,
-                                                               float divisor) {
+                                                               float divisor, InMask im, OutDrop od) {
     constexpr int kBM = 128, BN = 128, kBK = 32, MT = 2, NT = 2;
     constexpr int kAPitch = kBK + 4, kBPitch = BN + 4;
     __shared__ __attribute__((aligned(16))) float as[kBM * kAPitch];
@@ -522,12 +605,19 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_panels_kernel(int tiles_m, int
     const int b_step = TRANS_B ? 32 * (int)ldb * 4 : 8 * (int)ldb * 4;       // unit p -> p + 1
     const int b_kstep = TRANS_B ? kBK * 4 : kBK * (int)ldb * 4;              // one k stage
     float4 ra[4], rb[4];
+    // mask words of this thread's 4 rows for the stage being loaded (A_MASK): word = stage number
+    uint32_t rm[4];
+    const __amdgpu_buffer_rsrc_t res_m = whole_range_buffer(A_MASK ? im.bits + m0 * im.ld_words : nullptr);
+    const int m_voff = A_MASK ? (tid >> 3) * (int)im.ld_words * 4 : 0;
+    const int m_step = A_MASK ? 32 * (int)im.ld_words * 4 : 0;
+    const int m_shift = (tid & 7) * 4;
     auto load_stage = [&](int a_k, int b_k) {      // scalar byte offsets of the stage in A and in B
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x4v v = __builtin_bit_cast(
                 f32x4v, __builtin_amdgcn_raw_buffer_load_b128(res_a, a_voff, a_k + i * a_step, 0));
             ra[i] = make_float4(v.x, v.y, v.z, v.w);
+            if (A_MASK) rm[i] = __builtin_amdgcn_raw_buffer_load_b32(res_m, m_voff, (a_k >> 5) + i * m_step, 0);
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -540,7 +630,10 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_panels_kernel(int tiles_m, int
     float* const bs_w = TRANS_B ? bs + (tid >> 3) * kAPitch + (tid & 7) * 4 : bs + (tid >> 5) * kBPitch + (tid & 31) * 4;
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(as_w + 32 * i * kAPitch) = ra[i];
+        for (int i = 0; i < 4; ++i) {
+            if (A_MASK) ra[i] = masked_scaled4(ra[i], rm[i], m_shift, im);
+            *reinterpret_cast<float4*>(as_w + 32 * i * kAPitch) = ra[i];
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             *reinterpret_cast<float4*>(bs_w + (TRANS_B ? 32 * p * kAPitch : 8 * p * kBPitch)) = rb[p];
@@ -666,6 +759,63 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_panels_kernel(int tiles_m, int
             gated_store(std::false_type{});
         return;
     }
+    if (EPI == kEpiDrop) {
+        // C = dropout(act(A.B)): decision id = index_offset + drawn row * pitch + column.  The four lanes of a
+        // quad hold four consecutive columns of the same rows, i.e. (when pitch and index_offset are multiples
+        // of 4) the four ids of one hash: lane s of the quad hashes for the rows 8 t + s of a 32 x 32 tile and the
+        // quad passes the hashes round with DPP moves -- a quarter of the 64-bit multiplications.
+        const uint64_t key = od.stream_offset ? stream_key(od.seed, od.stream_id + *od.stream_offset) : od.key;
+        const bool scale_exact = (__float_as_uint(od.keep_prob) & 0x007fffffu) == 0;
+        const float inv_keep = 1.0f / od.keep_prob;
+        const bool quads = ((od.pitch | od.index_offset) & 3) == 0;
+        const int s4 = lane & 3;
+        const int field_shift = 16 * (1 - (s4 & 1));
+        auto finish = [&](float v, bool kept) {
+            if (relu) asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(v));
+            const float q = scale_exact ? v * inv_keep : __fdiv_rn(v, od.keep_prob);
+            return kept ? q : 0.0f;
+        };
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int64_t row0 = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);    // row of element e: row0 + (e & 3) + 8 (e >> 2)
+                const int64_t col = n0 + (wn * NT + j) * 32 + l31;
+                if (quads) {
+                    uint32_t h_lo[4], h_hi[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int64_t gr = row0 + s4 + 8 * t;
+                        const int64_t drawn = od.row_ids ? od.row_ids[gr] : gr;
+                        const uint64_t h = decision_hash(key, (uint64_t)(od.index_offset + drawn * od.pitch + (col - s4)));
+                        h_lo[t] = (uint32_t)h;
+                        h_hi[t] = (uint32_t)(h >> 32);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2);
+                        const uint32_t lo = quad_read(h_lo[e >> 2], e & 3);
+                        const uint32_t hi = quad_read(h_hi[e >> 2], e & 3);
+                        const uint32_t field = ((s4 < 2 ? hi : lo) >> field_shift) & 0xffffu;   // field s4 of the hash
+                        const float v = finish(acc[i][j][e], field >= od.threshold);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), res_c, c_voff,
+                                                              (row * (int)ldc + (wn * NT + j) * 32) * 4, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2);
+                        const int64_t gr = row0 + (e & 3) + 8 * (e >> 2);
+                        const int64_t drawn = od.row_ids ? od.row_ids[gr] : gr;
+                        const uint64_t id = (uint64_t)(od.index_offset + drawn * od.pitch + col);
+                        const float v = finish(acc[i][j][e], keep_field(decision_hash(key, id), id, od.threshold));
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), res_c, c_voff,
+                                                              (row * (int)ldc + (wn * NT + j) * 32) * 4, 0);
+                    }
+                }
+            }
+        return;
+    }
     if (relu) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -705,36 +855,61 @@ static bool panels_form_fits(int64_t m, int64_t n, int64_t k, const float* a, in
     return m / 128 <= 8 * 65535;
 }
 
+static const InMask kNoInMask = {nullptr, 0, 1.0f, 1.0f, 1};
+
 template <int kBM, int BN>
 static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
                        int trans_b, float* c, int64_t ldc, int relu, hipStream_t st, const float* gate = nullptr,
-                       int64_t ldg = 0, float divisor = 1.0f, const OutDrop* out_drop = nullptr) {
-    if (kBM == 128 && BN == 128 && !out_drop && panels_form_fits(m, n, k, a, lda, b, ldb, trans_b, ldc, gate, ldg)) {
+                       int64_t ldg = 0, float divisor = 1.0f, const OutDrop* out_drop = nullptr,
+                       const InMask* in_mask = nullptr) {
+    const InMask im = in_mask ? *in_mask : kNoInMask;
+    const OutDrop no_drop = {0, 1.0f, 0, 0, nullptr, 0, 0, nullptr, 0};
+    // the byte offset of a mask word inside a panel's buffer stays below 2^31 like every other offset
+    const bool mask_fits = !im.bits || (!trans_b && !gate && !out_drop && 128 * im.ld_words + k / 32 < ((int64_t)1 << 29));
+    if (kBM == 128 && BN == 128 && mask_fits && panels_form_fits(m, n, k, a, lda, b, ldb, trans_b, ldc, gate, ldg)) {
         // whole 128-row panels through the kernel without guards, the rows left over through the general one
         const int64_t panels = m / 128;
         const dim3 grid((unsigned)(8 * (n / 128)), (unsigned)ceil_div(panels, 8));
-#define GCN_PANELS_GO(TB, EPI)                                                                                \
-    gemm_panels_kernel<TB, EPI><<<grid, kBlock, 0, st>>>((int)panels, (int)(k / 32), a, lda, b, ldb, c, ldc, relu, gate, \
-                                                         ldg, divisor)
-        if (gate) {
+#define GCN_PANELS_GO(TB, EPI, AM)                                                                                \
+    gemm_panels_kernel<TB, EPI, AM><<<grid, kBlock, 0, st>>>((int)panels, (int)(k / 32), a, lda, b, ldb, c, ldc, relu, gate, \
+                                                             ldg, divisor, im, out_drop ? out_drop_ready(*out_drop) : no_drop)
+        if (im.bits) {
+            GCN_PANELS_GO(false, kEpiPlain, true);
+        } else if (out_drop) {
             if (trans_b)
-                GCN_PANELS_GO(true, kEpiGate);
+                GCN_PANELS_GO(true, kEpiDrop, false);
             else
-                GCN_PANELS_GO(false, kEpiGate);
+                GCN_PANELS_GO(false, kEpiDrop, false);
+        } else if (gate) {
+            if (trans_b)
+                GCN_PANELS_GO(true, kEpiGate, false);
+            else
+                GCN_PANELS_GO(false, kEpiGate, false);
         } else {
             if (trans_b)
-                GCN_PANELS_GO(true, kEpiPlain);
+                GCN_PANELS_GO(true, kEpiPlain, false);
             else
-                GCN_PANELS_GO(false, kEpiPlain);
+                GCN_PANELS_GO(false, kEpiPlain, false);
         }
 #undef GCN_PANELS_GO
         GCN_LAUNCH_CHECK();
         const int64_t done = panels * 128;
         if (done == m) return GCN_OK;
+        // the rows left over: their decisions and mask words are those of rows `done` onwards
+        OutDrop rest_drop = out_drop ? *out_drop : no_drop;
+        if (out_drop) {
+            if (rest_drop.row_ids)
+                rest_drop.row_ids += done;
+            else
+                rest_drop.index_offset += done * rest_drop.pitch;
+        }
+        InMask rest_mask = im;
+        if (im.bits) rest_mask.bits += done * im.ld_words;
         return launch_gemm<kBM, BN>(m - done, n, k, a + done * lda, lda, b, ldb, trans_b, c + done * ldc, ldc, relu, st,
-                                    gate ? gate + done * ldg : nullptr, ldg, divisor, nullptr);
+                                    gate ? gate + done * ldg : nullptr, ldg, divisor, out_drop ? &rest_drop : nullptr,
+                                    im.bits ? &rest_mask : nullptr);
     }
-    const OutDrop od = out_drop ? *out_drop : OutDrop{0, 1.0f, 0, 0, nullptr, 0, 0};
+    const OutDrop od = out_drop ? out_drop_ready(*out_drop) : OutDrop{0, 1.0f, 0, 0, nullptr, 0, 0};
     const int64_t tiles_m = ceil_div(m, kBM), tiles_n = ceil_div(n, BN);
     const int64_t n_tiles = tiles_m * tiles_n;
     if (n_tiles > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
@@ -742,7 +917,7 @@ static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
     const int b_vec = (ldb % 4 == 0) && (((uintptr_t)b & 15) == 0);
 #define GCN_GEMM_GO(TB, BK)                                                                                  \
     gemm_mfma_kernel<kBM, BN, TB, BK><<<(unsigned)n_tiles, kBlock, 0, st>>>(m, n, k, a, lda, b, ldb, c, ldc, relu, a_vec, \
-                                                                       b_vec, tiles_m, tiles_n, gate, ldg, divisor, od)
+                                                                       b_vec, tiles_m, tiles_n, gate, ldg, divisor, od, im)
     if (k <= 16) {
         if (trans_b)
             GCN_GEMM_GO(true, 16);
@@ -775,7 +950,8 @@ template <int TM, int BN, bool BUF>
 __global__ __launch_bounds__(64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)), 3)
 void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a, int64_t lda,
                     const float* __restrict__ g, int64_t ldg, float* __restrict__ out, int64_t ldo,
-                    int64_t split_stride, int64_t rows_per_split, int vec_ok, int tiles_n, int tiles, int splits) {
+                    int64_t split_stride, int64_t rows_per_split, int vec_ok, int tiles_n, int tiles, int splits,
+                    InMask im) {
     constexpr int kTiles = (TM / 32) * (BN / 32);
     constexpr int kWaves = kTiles > 4 ? 4 : kTiles;
     constexpr int kThreads = 64 * kWaves;
@@ -810,11 +986,20 @@ void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     float4 rx[kXPer], rg[kGPer];
+    // input dropout on A (im.bits): the mask of the forward pass, read again -- a float4 of A holds 4
+    // consecutive columns of one row, all inside one mask word
+    auto mask_x = [&](int p, int64_t gr, int64_t gc) {
+        if (im.bits) {
+            const uint32_t word = (gr < r_end && gc < k) ? im.bits[gr * im.ld_words + (gc >> 5)] : 0u;
+            rx[p] = masked_scaled4(rx[p], word, (int)(gc & 31), im);
+        }
+    };
     auto load_fast = [&](int64_t r0) {
 #pragma unroll
         for (int p = 0; p < kXPer; ++p) {
             const int u = tid + kThreads * p;
             rx[p] = *reinterpret_cast<const float4*>(a + (r0 + u / (TM / 4)) * lda + k0 + (u % (TM / 4)) * 4);
+            mask_x(p, r0 + u / (TM / 4), k0 + (u % (TM / 4)) * 4);
         }
 #pragma unroll
         for (int p = 0; p < kGPer; ++p) {
@@ -838,6 +1023,7 @@ void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a
         for (int p = 0; p < kXPer; ++p) {
             const int u = tid + kThreads * p;
             rx[p] = guarded_unit(a, lda, r0 + u / (TM / 4), k0 + (u % (TM / 4)) * 4, k);
+            mask_x(p, r0 + u / (TM / 4), k0 + (u % (TM / 4)) * 4);
         }
 #pragma unroll
         for (int p = 0; p < kGPer; ++p) {
@@ -894,15 +1080,25 @@ void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a
         const int x_voff = ((tid >> 5) * (int)lda + (tid & 31) * 4) * 4;
         const int g_voff = ((tid >> 5) * (int)ldg + (tid & 31) * 4) * 4;
         const int x_unit = 8 * (int)lda * 4, g_unit = 8 * (int)ldg * 4;
-        int x_stage = 0, g_stage = 0;
+        // mask words (input dropout on A): row tid / 32 + 8 p of the stage, word (k0 + 4 (tid % 32)) / 32
+        const bool masked = im.bits != nullptr;
+        const __amdgpu_buffer_rsrc_t res_m =
+            whole_range_buffer(masked ? im.bits + r_begin * im.ld_words + (k0 >> 5) : nullptr);
+        const int m_voff = masked ? ((tid >> 5) * (int)im.ld_words + ((tid & 31) >> 3)) * 4 : 0;
+        const int m_unit = masked ? 8 * (int)im.ld_words * 4 : 0;
+        const int m_shift = (tid & 7) * 4;
+        int x_stage = 0, g_stage = 0, m_stage = 0;
         for (; t + 1 < n_full; ++t) {
             x_stage += kRows * (int)lda * 4;
             g_stage += kRows * (int)ldg * 4;
+            m_stage += masked ? kRows * (int)im.ld_words * 4 : 0;
+            uint32_t rm[kXPer];
 #pragma unroll
             for (int p = 0; p < kXPer; ++p) {
                 const f32x4v v = __builtin_bit_cast(
                     f32x4v, __builtin_amdgcn_raw_buffer_load_b128(res_x, x_voff, x_stage + p * x_unit, 0));
                 rx[p] = make_float4(v.x, v.y, v.z, v.w);
+                if (masked) rm[p] = __builtin_amdgcn_raw_buffer_load_b32(res_m, m_voff, m_stage + p * m_unit, 0);
             }
 #pragma unroll
             for (int p = 0; p < kGPer; ++p) {
@@ -912,6 +1108,10 @@ void gemm_tn_kernel(int64_t m, int64_t n, int64_t k, const float* __restrict__ a
             }
             compute();
             __syncthreads();
+            if (masked) {
+#pragma unroll
+                for (int p = 0; p < kXPer; ++p) rx[p] = masked_scaled4(rx[p], rm[p], m_shift, im);
+            }
             store_tile();
             __syncthreads();
         }
@@ -1008,18 +1208,19 @@ int gcn_dropout_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, cons
         if (vblocks > (1 << 22)) vblocks = 1 << 22;
         if (keep_prob < 1.0f)
             dropout_vec_kernel<true><<<(unsigned)vblocks, kBlock, 0, (hipStream_t)stream>>>(
-                n_vec, (const float4*)x, (const float4*)gate, (float4*)y, keep_prob, stream_key(seed, stream_id),
-                index_offset, stream_offset, seed, stream_id);
+                n_vec, (const float4*)x, (const float4*)gate, (float4*)y, keep_prob, keep_threshold(keep_prob),
+                stream_key(seed, stream_id), index_offset, stream_offset, seed, stream_id);
         else
             dropout_vec_kernel<false><<<(unsigned)vblocks, kBlock, 0, (hipStream_t)stream>>>(
-                n_vec, (const float4*)x, (const float4*)gate, (float4*)y, keep_prob, 0, index_offset, nullptr, 0, 0);
+                n_vec, (const float4*)x, (const float4*)gate, (float4*)y, keep_prob, 0, 0, index_offset, nullptr, 0, 0);
         GCN_LAUNCH_CHECK();
         return GCN_OK;
     }
     int64_t blocks = ceil_div(total, kBlock);
     if (blocks > 256 * 32) blocks = 256 * 32;
     dropout_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_rows, f, x, ldx, gate, ldg, y, ldy,
-                                                                        keep_prob, stream_key(seed, stream_id), index_offset,
+                                                                        keep_prob, keep_threshold(keep_prob),
+                                                                        stream_key(seed, stream_id), index_offset,
                                                                         stream_offset, seed, stream_id);
     GCN_LAUNCH_CHECK();
     return GCN_OK;
@@ -1100,8 +1301,8 @@ int gcn_gemm_tn_workspace_bytes(int64_t m, int64_t n, int64_t k, size_t* bytes) 
     return GCN_OK;
 }
 
-int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* g, int64_t ldg,
-                    float* c, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream) {
+static int gemm_tn_entry(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* g, int64_t ldg,
+                         float* c, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream, const InMask& im) {
     if (m < 0 || n < 0 || k < 0) return fail(GCN_ERR_BAD_ARG, "negative dimension");
     if (lda < k || ldg < n || ldc < n) return fail(GCN_ERR_BAD_ARG, "leading dimension too small");
     if (k == 0 || n == 0) return GCN_OK;
@@ -1125,9 +1326,10 @@ int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda
 #define GCN_TN_GO(TM, BN, BUF)                                                                                     \
     gemm_tn_kernel<TM, BN, BUF><<<grid, 64 * ((TM / 32) * (BN / 32) > 4 ? 4 : (TM / 32) * (BN / 32)), 0, st>>>(      \
         m, n, k, a, lda, g, ldg, out, ldo, split_stride, s.rows_per_split, vec_ok, (int)s.tiles_n, (int)s.tiles,    \
-        (int)s.splits)
+        (int)s.splits, im)
     // byte offsets inside one row range of a block stay below 2^31
-    const bool buf_ok = vec_ok && (s.rows_per_split + 32) * std::max(lda, ldg) < ((int64_t)1 << 29);
+    const bool buf_ok = vec_ok && (s.rows_per_split + 32) * std::max(std::max(lda, ldg), im.bits ? im.ld_words : 0) <
+                                      ((int64_t)1 << 29);
     if (s.tm == 128 && s.bn == 128 && buf_ok)
         GCN_TN_GO(128, 128, true);
     else if (s.tm == 128 && s.bn == 128)
@@ -1145,6 +1347,69 @@ int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda
         reduce_splits_kernel<<<(unsigned)blocks, kBlock, 0, st>>>(k, n, s.splits, out, c, ldc);
         GCN_LAUNCH_CHECK();
     }
+    return GCN_OK;
+}
+
+static int make_in_mask(const uint32_t* bits, int64_t ld_words, int64_t width, float keep_prob, InMask* im) {
+    if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
+    if (!bits) return fail(GCN_ERR_BAD_ARG, "mask is null");
+    if (ld_words < (width + 31) / 32)
+        return fail(GCN_ERR_BAD_ARG, "mask rows of %lld words cannot hold %lld bits", (long long)ld_words, (long long)width);
+    im->bits = bits;
+    im->ld_words = ld_words;
+    im->keep_prob = keep_prob;
+    im->inv_keep = 1.0f / keep_prob;
+    uint32_t u;
+    memcpy(&u, &keep_prob, 4);
+    im->exact = (u & 0x007fffffu) == 0;
+    return GCN_OK;
+}
+
+int gcn_gemm_tn_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* g, int64_t ldg,
+                    float* c, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_tn_entry(m, n, k, a, lda, g, ldg, c, ldc, workspace, workspace_bytes, stream, kNoInMask);
+}
+
+int gcn_gemm_tn_masked_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const uint32_t* mask,
+                           int64_t ld_words, float keep_prob, const float* g, int64_t ldg, float* c, int64_t ldc,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    InMask im;
+    const int rc = make_in_mask(mask, ld_words, k, keep_prob, &im);
+    if (rc != GCN_OK) return rc;
+    return gemm_tn_entry(m, n, k, a, lda, g, ldg, c, ldc, workspace, workspace_bytes, stream, im);
+}
+
+int gcn_gemm_masked_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const uint32_t* mask,
+                        int64_t ld_words, float keep_prob, const float* b, int64_t ldb, int trans_b, float* c,
+                        int64_t ldc, int flags, void* stream) {
+    if (m < 0 || n < 0 || k < 0) return fail(GCN_ERR_BAD_ARG, "negative dimension");
+    if (lda < k || ldc < n || ldb < (trans_b ? k : n)) return fail(GCN_ERR_BAD_ARG, "leading dimension too small");
+    if (flags & ~GCN_RELU) return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    InMask im;
+    const int rc = make_in_mask(mask, ld_words, k, keep_prob, &im);
+    if (rc != GCN_OK) return rc;
+    if (m == 0 || n == 0) return GCN_OK;
+    if (!c || (k > 0 && (!a || !b))) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int relu = (flags & GCN_RELU) ? 1 : 0;
+    if (n <= 32) return launch_gemm<128, 32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st, nullptr, 0, 1.0f, nullptr, &im);
+    if (n <= 64) return launch_gemm<128, 64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st, nullptr, 0, 1.0f, nullptr, &im);
+    return launch_gemm<128, 128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st, nullptr, 0, 1.0f, nullptr, &im);
+}
+
+int gcn_dropout_bits(int64_t n_rows, int64_t f, float keep_prob, uint64_t seed, uint64_t stream_id,
+                     const uint64_t* stream_offset, uint64_t index_offset, int64_t pitch, uint32_t* bits_out,
+                     int64_t ld_words, void* stream) {
+    if (n_rows < 0 || f < 0 || pitch < f || ld_words < (f + 31) / 32) return fail(GCN_ERR_BAD_ARG, "bad shape");
+    if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
+    const int64_t words = (f + 31) / 32;
+    if (n_rows == 0 || words == 0) return GCN_OK;
+    if (!bits_out) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    const int64_t blocks = std::min<int64_t>(ceil_div(n_rows * words, kBlock), 1 << 20);
+    dropout_bits_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(
+        n_rows, f, words, keep_threshold(keep_prob), stream_key(seed, stream_id), index_offset, pitch, bits_out, ld_words,
+        stream_offset, seed, stream_id);
+    GCN_LAUNCH_CHECK();
     return GCN_OK;
 }
 

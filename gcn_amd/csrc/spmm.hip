@@ -209,6 +209,7 @@ struct DropArgs {
     // a launch recorded in a HIP graph then draws a new mask on every replay
     const uint64_t* stream_offset;
     uint64_t seed, stream_id;
+    uint32_t threshold;   // keep_threshold(keep_prob): an entry is kept iff its 16-bit field is >= this
 };
 
 // sparse_dropout decisions of one batch of U entries starting at kb, for a lane group of LPR lanes.
@@ -237,7 +238,7 @@ __device__ __forceinline__ void drop_decisions(const DropArgs& dr, const DropIds
                                                bool (&kept)[U]) {
 #pragma unroll
     for (int j = 0; j < DropIds<LPR, U>::kRounds; ++j) {
-        const uint64_t bits = __ballot(keep_entry(dr.key, ids.v[j], dr.keep_prob));
+        const uint64_t bits = __ballot(keep_field(decision_hash(dr.key, ids.v[j]), ids.v[j], dr.threshold));
 #pragma unroll
         for (int i = 0; i < LPR; ++i)
             if (j * LPR + i < U) kept[j * LPR + i] = (bits >> (group_base + i)) & 1ull;
@@ -402,9 +403,14 @@ __device__ __forceinline__ void store_row(float* dst, const float* addend, const
             }
             if (od.keep_prob < 1.0f) {  // TF 1.x: div(x, keep_prob) * floor(keep_prob + uniform)
                 const uint64_t id = (uint64_t)(od.index_offset + row * od.pitch + col[v]);
+                // four consecutive ids starting at a multiple of 4 share one hash
+                const bool one_hash = VEC == 4 && (id & 3) == 0;
+                const uint64_t h4 = one_hash ? decision_hash(od.key, id) : 0;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    acc[v][e] = keep_entry(od.key, id + e, od.keep_prob) ? __fdiv_rn(acc[v][e], od.keep_prob) : 0.0f;
+                for (int e = 0; e < VEC; ++e) {
+                    const uint64_t h = one_hash ? h4 : decision_hash(od.key, id + e);
+                    acc[v][e] = keep_field(h, id + e, od.threshold) ? __fdiv_rn(acc[v][e], od.keep_prob) : 0.0f;
+                }
             }
             store_vec<VEC>(dst + col[v], acc[v]);
         }
@@ -803,7 +809,8 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(int64_t n_long
             const uint64_t id = (uint64_t)(od.index_offset + (int64_t)long_row[li] * od.pitch + j);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                s[e] = keep_entry(od.key, id + e, od.keep_prob) ? __fdiv_rn(s[e], od.keep_prob) : 0.0f;
+                s[e] = keep_field(decision_hash(od.key, id + e), id + e, od.threshold) ? __fdiv_rn(s[e], od.keep_prob)
+                                                                                       : 0.0f;
         }
         if (vec_c) {
             store_vec<4>(dst + j, s);
@@ -963,7 +970,7 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
     a.dr = dr;
     a.add = add;
     a.ldadd = ldadd;
-    a.od = od ? *od : OutDrop{0, 1.0f, 0, 0, nullptr, 0, 0};
+    a.od = od ? out_drop_ready(*od) : OutDrop{0, 1.0f, 0, 0, nullptr, 0, 0};
     a.st = (hipStream_t)stream;
     const int64_t max_chunks = std::max(plan->table[0].n_chunks, plan->table[1].n_chunks);
     if (max_chunks > 0) {
@@ -1246,7 +1253,8 @@ int gcn_spmm_csr_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, c
                              const uint64_t* stream_offset,
                              void* workspace, size_t workspace_bytes, void* stream) {
     if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
-    DropArgs dr = {perm, stream_key(seed, stream_id), keep_prob, 1.0f / keep_prob, stream_offset, seed, stream_id};
+    DropArgs dr = {perm, stream_key(seed, stream_id), keep_prob, 1.0f / keep_prob, stream_offset, seed, stream_id,
+                   keep_threshold(keep_prob)};
     return spmm_entry<true>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
                             stream);
 }

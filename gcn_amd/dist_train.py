@@ -13,7 +13,7 @@ import torch
 from . import graph, sparse
 from .dist import (HaloPlan, all_gather_rows, all_reduce_sum, column_chunks, column_shares, halo_product,
                    shard_rows_compacted, shard_with_columns, shard_with_rows)
-from .layers import _GatedGemmFn, _GemmFn
+from .layers import _DroppedInputGemmFn, _GatedGemmFn, _GemmFn
 from .models import TfAdam
 
 
@@ -266,10 +266,17 @@ class ShardedGCN(object):
                 s = _product(self.plan, h, False, self.chunks)
                 h = _AggregatedFirstLayerFn.apply(s, w, li != last, next_drop)
                 continue
-            if drop and li == 0:
-                offset = self.shard.row_begin * h.shape[1]
-                h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64, offset)
-            p = _GatedGemmFn.apply(h, w, keep) if drop and li > 0 else _GemmFn.apply(h, w)
+            if drop and li == 0 and not h.requires_grad:
+                # the features take no gradient: their dropout is drawn as bits and applied inside the
+                # product X' . W0 and inside its weight gradient (the same decisions as a pass over X)
+                bits = sparse.dropout_bits(h.shape[0], h.shape[1], keep, self.seed, self.step_count * 64,
+                                           index_offset=self.shard.row_begin * h.shape[1], device=h.device)
+                p = _DroppedInputGemmFn.apply(h, w, bits, keep)
+            else:
+                if drop and li == 0:
+                    offset = self.shard.row_begin * h.shape[1]
+                    h = _ShardDropoutFn.apply(h, keep, self.seed, self.step_count * 64, offset)
+                p = _GatedGemmFn.apply(h, w, keep) if drop and li > 0 else _GemmFn.apply(h, w)
             if li == last and logit_plans is not None:     # a training step: labelled rows forward, labelled columns backward
                 h = _HaloSpmmFn.apply(logit_plans[0], p, False, self.chunks, not drop, None, logit_plans[1])
             else:

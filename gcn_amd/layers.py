@@ -101,6 +101,27 @@ class _GemmFn(torch.autograd.Function):
         return ga, gw
 
 
+class _DroppedInputGemmFn(torch.autograd.Function):
+    """dropout(x) . W for a layer input x that needs no gradient (the features), the dropout applied to x as
+    the product loads it: tf.nn.dropout (gcn/layers.py:185) and tf.matmul (gcn/layers.py:198-199) in one
+    kernel.  The decisions live in a bit matrix (1/32 of the bytes of x); the weight gradient
+    dropout(x)^T . dOut reads x and the same bits, so the dropped matrix is never written."""
+
+    @staticmethod
+    def forward(ctx, x, w, bits, keep_prob):
+        ctx.save_for_backward(x, bits)
+        ctx.keep_prob = keep_prob
+        return sparse.gemm_masked(x, bits, keep_prob, w)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, bits = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError('the dropped layer input of _DroppedInputGemmFn takes no gradient')
+        d_w = sparse.gemm_tn_masked(x, bits, ctx.keep_prob, grad.contiguous()) if ctx.needs_input_grad[1] else None
+        return None, d_w, None, None
+
+
 class _GatedGemmFn(torch.autograd.Function):
     """h_dropped . W where h_dropped = dropout(relu(z)) came out of a product's store (_SpmmFn with
     ``out_dropout``).  The gradient it returns for its left operand is the gradient of z:

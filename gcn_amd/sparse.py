@@ -561,6 +561,66 @@ def dropout(x, keep_prob, seed, stream_id, gate=None, index_offset=0):
     return y
 
 
+def dropout_bits(n_rows, f, keep_prob, seed, stream_id, index_offset=0, pitch=None, device='cuda'):
+    """The decisions ``dropout`` would draw for a matrix [n_rows x f], one bit per element: an int32 tensor
+    [n_rows x ceil(f / 32)] whose bit c % 32 of word c / 32 of row r is 1 iff element (r, c) is kept.
+    ``gemm_masked`` / ``gemm_tn_masked`` apply them to their left operand as they load it."""
+    words = (int(f) + 31) // 32
+    bits = torch.empty((int(n_rows), words), dtype=torch.int32, device=device)
+    _lib.call('gcn_dropout_bits', int(n_rows), int(f), float(keep_prob), int(seed), int(stream_id), _p(_stream_offset),
+              int(index_offset), int(f if pitch is None else pitch), _p(bits), words, _stream())
+    return bits
+
+
+def _check_bits(bits, m, k):
+    _require_cuda(bits)
+    if bits.dtype != torch.int32 or bits.dim() != 2 or bits.shape[0] != m or bits.shape[1] * 32 < k \
+            or (bits.shape[1] > 1 and bits.stride(1) != 1):
+        raise ValueError('mask bits must be an int32 [%d x >= %d] tensor' % (m, (k + 31) // 32))
+    return bits.stride(0) if m > 1 else bits.shape[1]
+
+
+def gemm_masked(a, bits, keep_prob, b, trans_b=False, relu=False, out=None):
+    """``dropout(a) @ b`` with the dropout applied to ``a`` as the product loads it (``bits`` from
+    ``dropout_bits``): the bits of ``gemm(dropout(a, ...), b)`` without the pass that writes the dropped matrix."""
+    _require_cuda(a, b)
+    a, b = _rowmajor(a), _rowmajor(b)
+    m, k = a.shape
+    n = b.shape[0] if trans_b else b.shape[1]
+    if (b.shape[1] if trans_b else b.shape[0]) != k:
+        raise ValueError('shape mismatch in gemm_masked')
+    ld_words = _check_bits(bits, m, k)
+    if out is None:
+        c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    else:
+        _check_out(out, m, n)
+        c = out
+    _lib.call('gcn_gemm_masked_f32', m, n, k, _p(a), _ld(a), _p(bits), ld_words, float(keep_prob), _p(b), _ld(b),
+              1 if trans_b else 0, _p(c), _ld(c), _lib.GCN_RELU if relu else 0, _stream())
+    return c
+
+
+def gemm_tn_masked(a, bits, keep_prob, g, out=None):
+    """``dropout(a).T @ g`` with the same mask bits: the weight gradient of the layer ``gemm_masked`` computes."""
+    _require_cuda(a, g)
+    a, g = _rowmajor(a), _rowmajor(g)
+    m, k = a.shape
+    if g.shape[0] != m:
+        raise ValueError('shape mismatch in gemm_tn_masked')
+    n = g.shape[1]
+    ld_words = _check_bits(bits, m, k)
+    if out is None:
+        out = torch.empty((k, n), dtype=torch.float32, device=a.device)
+    else:
+        _check_out(out, k, n)
+    nbytes = ctypes.c_size_t()
+    _lib.call('gcn_gemm_tn_workspace_bytes', m, n, k, ctypes.byref(nbytes))
+    ws = _workspace(nbytes.value, a.device) if nbytes.value else None
+    _lib.call('gcn_gemm_tn_masked_f32', m, n, k, _p(a), _ld(a), _p(bits), ld_words, float(keep_prob), _p(g), _ld(g),
+              _p(out), _ld(out), _p(ws), nbytes.value, _stream())
+    return out
+
+
 def gemm(a, b, trans_b=False, relu=False, out=None, out_dropout=None):
     """``a @ b`` (or ``a @ b.T``) in float32 on the MFMA pipe.  ``out_dropout`` (an OutDropout): the result
     is written already dropped, after the ReLU."""

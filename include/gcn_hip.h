@@ -329,6 +329,29 @@ int gcn_gemm_out_dropout_f32(int64_t m, int64_t n, int64_t k, const float* a, in
                              uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
                              const int64_t* row_ids, void* stream);
 
+/* The decisions of tf.nn.dropout (gcn/layers.py:185) on a matrix [n_rows x f] as one bit per element: bit
+ * c % 32 of word bits_out[r * ld_words + c / 32] is 1 iff element (r, c) is kept.  Element (r, c) draws the
+ * decision of id index_offset + r * pitch + c -- the one gcn_dropout_f32 draws (there pitch = f).  With the
+ * two products below the dropped matrix is never written: the layer that consumes it reads x and the bits
+ * (1/32 of the bytes), forward and backward. */
+int gcn_dropout_bits(int64_t n_rows, int64_t f, float keep_prob, uint64_t seed, uint64_t stream_id,
+                     const uint64_t* stream_offset, uint64_t index_offset, int64_t pitch, uint32_t* bits_out,
+                     int64_t ld_words, void* stream);
+
+/* C = dropout(A) . op(B): tf.nn.dropout on a dense layer input (gcn/layers.py:185) followed by tf.matmul
+ * (gcn/layers.py:198-199, 32-33), the dropout applied to A's elements as they are loaded: element (r, kk) of
+ * A becomes A[r, kk] / keep_prob if bit (r, kk) of `mask` (gcn_dropout_bits, rows of ld_words words) is set,
+ * else 0.  Same bits as gcn_dropout_f32 followed by gcn_gemm_f32. */
+int gcn_gemm_masked_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const uint32_t* mask,
+                        int64_t ld_words, float keep_prob, const float* b, int64_t ldb, int trans_b, float* c,
+                        int64_t ldc, int flags, void* stream);
+
+/* C[k x n] = dropout(A)^T . G with the same mask: the weight gradient of that layer (gcn/models.py:86).
+ * Workspace as for gcn_gemm_tn_f32; same bits as gcn_dropout_f32 followed by gcn_gemm_tn_f32. */
+int gcn_gemm_tn_masked_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const uint32_t* mask,
+                           int64_t ld_words, float keep_prob, const float* g, int64_t ldg, float* c, int64_t ldc,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* C[k x n] = A^T . G for A [m x k] and G [m x n], both row-major: the weight gradient
  * dW = H^T . dP that tf.train.AdamOptimizer.minimize derives for tf.matmul and for
  * tf.sparse_tensor_dense_matmul with a dense left operand (gcn/models.py:86, gcn/layers.py:28-34).

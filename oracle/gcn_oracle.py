@@ -44,15 +44,18 @@ def stream_key(seed, stream=0):
     return sm64(sm64(_U64(seed)) ^ _U64(stream))
 
 
-def uniform24(key, idx):
-    """u in [0,1) with 24 random bits: (sm64(key ^ idx) >> 40) * 2^-24, float32."""
-    h = sm64(_U64(key) ^ np.asarray(idx, dtype=np.uint64))
-    return (h >> _U64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+def uniform16(key, idx):
+    """u in [0,1) with 16 random bits, float32.  One hash serves four consecutive ids: h = sm64(key ^ (idx >> 2))
+    and id idx reads the 16-bit field idx & 3 of h, most significant field first; u = field * 2^-16."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    h = sm64(_U64(key) ^ (idx >> _U64(2)))
+    shift = _U64(48) - _U64(16) * (idx & _U64(3))
+    return ((h >> shift) & _U64(0xFFFF)).astype(np.float32) * np.float32(2.0 ** -16)
 
 
 def keep_mask(key, idx, keep_prob):
     """Dropout predicate of gcn/layers.py:21-23: floor(keep_prob + u) == 1, in float32."""
-    u = uniform24(key, idx)
+    u = uniform16(key, idx)
     return np.floor(np.float32(keep_prob) + u) >= np.float32(1.0)
 
 

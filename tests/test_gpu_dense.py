@@ -293,3 +293,69 @@ def test_dropout_store_of_a_row_subset_draws_the_rows_own_decisions(oracle):
     rows = torch.sort(torch.randperm(m, generator=torch.Generator().manual_seed(1))[:1111])[0].cuda()
     part = sparse.gemm(a[rows].contiguous(), b, relu=True, out_dropout=sparse.OutDropout(0.5, 5, 6, pitch=n, row_ids=rows))
     assert torch.equal(part, full[rows])
+
+
+@pytest.mark.parametrize('m,n,k', [(640, 128, 64), (1000, 256, 96), (4096, 256, 256), (77, 16, 40), (300, 7, 16),
+                                    (513, 130, 33)])
+@pytest.mark.parametrize('keep', [0.5, 0.8])
+def test_dropout_in_the_left_operand_load_equals_the_separate_pass(oracle, m, n, k, keep):
+    """gcn_dropout_bits + gcn_gemm_masked_f32 / gcn_gemm_tn_masked_f32: the dropout of a layer input applied as
+    the product loads it.  The bits are the oracle's decisions; both products give the bits of the same
+    product on the matrix a separate dropout pass writes (whole panels, ragged shapes, row blocks)."""
+    import torch
+    from gcn_amd import sparse
+    seed, stream, first_row = 21, 5, 1000
+    a = _t(oracle.synthetic_dense(m, k, seed=61))
+    b = _t(oracle.synthetic_dense(k, n, seed=62))
+    g = _t(oracle.synthetic_dense(m, n, seed=63))
+    bits = sparse.dropout_bits(m, k, keep, seed, stream, index_offset=first_row * k)
+    dropped = sparse.dropout(a, keep, seed, stream, index_offset=first_row * k)
+    _, kept = oracle.dense_dropout(a.cpu().numpy(), np.float32(keep), oracle.stream_key(seed, stream),
+                                   index_offset=first_row * k)
+    words = bits.cpu().numpy().view(np.uint32)
+    unpacked = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(m, -1)[:, :k].astype(bool)
+    assert np.array_equal(unpacked, kept)
+    assert np.array_equal(unpacked, dropped.cpu().numpy() != 0) or (a == 0).any()
+    assert torch.equal(sparse.gemm_masked(a, bits, keep, b), sparse.gemm(dropped, b))
+    assert torch.equal(sparse.gemm_masked(a, bits, keep, b, relu=True), sparse.gemm(dropped, b, relu=True))
+    assert torch.equal(sparse.gemm_masked(a, bits, keep, b.t().contiguous(), trans_b=True), sparse.gemm(dropped, b))
+    assert torch.equal(sparse.gemm_tn_masked(a, bits, keep, g), sparse.gemm_tn(dropped, g))
+    # strided operand and mask rows wider than needed
+    a_wide = torch.zeros((m, k + 8), device='cuda')
+    a_wide[:, 4:4 + k] = a
+    bits_wide = torch.zeros((m, bits.shape[1] + 3), dtype=torch.int32, device='cuda')
+    bits_wide[:, :bits.shape[1]] = bits
+    assert torch.equal(sparse.gemm_masked(a_wide[:, 4:4 + k], bits_wide[:, :bits.shape[1]], keep, b),
+                       sparse.gemm(dropped, b))
+    assert torch.equal(sparse.gemm_tn_masked(a_wide[:, 4:4 + k], bits_wide[:, :bits.shape[1]], keep, g),
+                       sparse.gemm_tn(dropped, g))
+
+
+@pytest.mark.parametrize('m,n,k', [(1280, 256, 256), (640, 128, 64), (1000, 384, 96)])
+@pytest.mark.parametrize('trans_b', [False, True])
+def test_dropout_store_of_whole_panels_equals_the_guarded_form(oracle, m, n, k, trans_b):
+    """The store with dropout on whole 128-row panels (one hash per element in the unguarded kernel's
+    epilogue) against the same problem posed so that it takes the guarded kernel (four more columns), and
+    against the product followed by a separate dropout pass; with row_ids and with a row block's offset."""
+    import torch
+    from gcn_amd import sparse
+    a = _t(oracle.synthetic_dense(m, k, seed=71))
+    b_wide = oracle.synthetic_dense(k, n + 4, seed=72)
+    if trans_b:
+        bw = _t(np.ascontiguousarray(b_wide.T))
+        b_part = bw[:n]
+    else:
+        bw = _t(b_wide)
+        b_part = bw[:, :n]
+    for keep in (0.5, 0.8):
+        drop = sparse.OutDropout(keep, 31, 7, index_offset=5 * (n + 4), pitch=n + 4)
+        guarded = sparse.gemm(a, bw, trans_b=trans_b, relu=True, out_dropout=drop)[:, :n]
+        panels = sparse.gemm(a, b_part, trans_b=trans_b, relu=True, out_dropout=drop)
+        assert torch.equal(panels, guarded)
+        plain = sparse.gemm(a, b_part, trans_b=trans_b, relu=True)
+        sep = sparse.dropout(plain, keep, 31, 7)
+        assert torch.equal(sparse.gemm(a, b_part, trans_b=trans_b, relu=True, out_dropout=sparse.OutDropout(keep, 31, 7)), sep)
+        ids = torch.randperm(3 * m, device='cuda')[:m].contiguous()
+        by_rows = sparse.OutDropout(keep, 31, 7, pitch=n + 4, row_ids=ids)
+        assert torch.equal(sparse.gemm(a, b_part, trans_b=trans_b, out_dropout=by_rows),
+                           sparse.gemm(a, bw, trans_b=trans_b, out_dropout=by_rows)[:, :n])

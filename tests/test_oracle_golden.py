@@ -109,12 +109,16 @@ def test_feature_triple_order(dataset_fx, oracle):
 
 
 def test_dropout_rule_and_counter_rng(oracle):
-    """keep iff floor(keep_prob + u) == 1 (layers.py:21-23); u has 24 bits and is reproducible."""
+    """keep iff floor(keep_prob + u) == 1 (layers.py:21-23); u has 16 bits, four consecutive ids share one
+    hash, and the stream is reproducible."""
     key = oracle.stream_key(1234, 6)
-    u = oracle.uniform24(key, np.arange(1 << 16))
+    u = oracle.uniform16(key, np.arange(1 << 16))
     assert u.dtype == np.float32 and u.min() >= 0 and u.max() < 1
-    assert np.array_equal(u, oracle.uniform24(key, np.arange(1 << 16)))
-    assert np.all(u * 2 ** 24 == np.round(u * 2 ** 24))
+    assert np.array_equal(u, oracle.uniform16(key, np.arange(1 << 16)))
+    assert np.all(u * 2 ** 16 == np.round(u * 2 ** 16))
+    h = oracle.sm64(np.uint64(key) ^ np.arange(1 << 14, dtype=np.uint64))            # id >> 2 of the ids above
+    fields = np.stack([(h >> np.uint64(48 - 16 * j)) & np.uint64(0xFFFF) for j in range(4)], axis=1).reshape(-1)
+    assert np.array_equal((u * 2 ** 16).astype(np.uint64), fields)
     assert abs(u.mean() - 0.5) < 0.01
     for keep_prob in (0.5, 0.9, 1.0):
         keep = oracle.keep_mask(key, np.arange(1 << 16), keep_prob)
