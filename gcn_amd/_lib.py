@@ -71,6 +71,8 @@ SIGNATURES = {
     'gcn_spmm_plan_last_timing': [_vp, ctypes.POINTER(ctypes.c_float)],
     'gcn_spmm_csr_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _sz, _vp],
     'gcn_spmm_csr_f32_noalloc': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp],
+    'gcn_spmm_csr_two_part_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64,
+                                  _vp, _i64, _i64, _vp, _sz, _vp],
     'gcn_spmm_csr_add_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _sz, _vp],
     'gcn_spmm_csr_dropout_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64,
                                  _vp, _vp, _sz, _vp],

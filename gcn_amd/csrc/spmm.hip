@@ -245,6 +245,26 @@ __device__ __forceinline__ void drop_decisions(const DropArgs& dr, const DropIds
     }
 }
 
+// A dense operand stored in two parts: its rows [0, n_first) at `first` (row pitch ld_first), the others in the
+// matrix the kernel is given as b -- whose pointer the host has moved back by n_first rows, so that row c of the
+// operand is b + c * ldb there too.  A row-sharded product reads its own block of rows where it lies and only the
+// rows received from other ranks from the exchange buffer: the own rows are never copied.
+struct TwoPart {
+    const float* first;
+    uint32_t ld_first;
+    uint32_t n_first;
+};
+template <bool SEG>
+__device__ __forceinline__ const float* operand_row(const float* b, uint32_t ldb, const TwoPart& tp, uint32_t c) {
+    if (SEG) {
+        const bool in_first = c < tp.n_first;
+        const float* base = in_first ? tp.first : b;
+        const uint32_t ld = in_first ? tp.ld_first : ldb;
+        return base + (uint64_t)c * (uint64_t)ld;
+    }
+    return b + (uint64_t)c * (uint64_t)ldb;
+}
+
 // acc += sum over entries k0..k1-1 (in order) of a_k * B[col_k, this lane's columns].
 // Entries are taken kUnroll at a time: the B rows of one batch and the (index, value) pairs of the
 // next batch are all in flight together.  Addresses past the end of the range are clamped to its
@@ -253,11 +273,12 @@ __device__ __forceinline__ void drop_decisions(const DropArgs& dr, const DropIds
 // NT (wave-per-row instances only: the column of an entry is the same in every lane): rows of B whose
 // column is >= hot are loaded with the non-temporal hint, so that they do not push the hub rows out of
 // the caches.
-template <int LPR, int VEC, int VPL, bool DROPOUT, bool NT = false>
+template <int LPR, int VEC, int VPL, bool DROPOUT, bool NT = false, bool SEG = false>
 __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const int32_t* __restrict__ indices,
                                                  const float* __restrict__ vals, const float* __restrict__ b,
                                                  uint32_t ldb, const int (&lcol)[VPL], const DropArgs& dr,
-                                                 float (&acc)[VPL][VEC], uint32_t hot = 0) {
+                                                 float (&acc)[VPL][VEC], uint32_t hot = 0,
+                                                 const TwoPart& tp = TwoPart{nullptr, 0, 0}) {
     if (k0 >= k1) return;
     const int64_t k_last = k1 - 1;
     const int sub = (threadIdx.x & 63) % LPR, group_base = (threadIdx.x & 63) - sub;
@@ -275,7 +296,7 @@ __device__ __forceinline__ void accumulate_range(int64_t k0, int64_t k1, const i
         float bv[kUnroll][VPL][VEC];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const float* brow = b + (uint64_t)c[u] * (uint64_t)ldb;
+            const float* brow = operand_row<SEG>(b, ldb, tp, c[u]);
             if (NT && (uint32_t)__builtin_amdgcn_readfirstlane((int)c[u]) >= hot) {
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) load_vec_nt<VEC>(brow + lcol[v], bv[u][v]);
@@ -417,13 +438,14 @@ __device__ __forceinline__ void store_row(float* dst, const float* addend, const
 }
 
 // rows of ordinary length; one wave per strip
-template <int LPR, int VEC, int VPL, bool DROPOUT, bool PIPED, bool NT = false>
+template <int LPR, int VEC, int VPL, bool DROPOUT, bool PIPED, bool NT = false, bool SEG = false>
 __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, const int32_t* __restrict__ strip_row,
                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                              uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
                                              const DropArgs& dr, int split, const float* __restrict__ add,
-                                             int64_t ldadd, const OutDrop& od, uint32_t hot = 0) {
+                                             int64_t ldadd, const OutDrop& od, uint32_t hot = 0,
+                                             const TwoPart& tp = TwoPart{nullptr, 0, 0}) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;  // columns covered per pass
     const int lane = threadIdx.x & 63;
@@ -455,7 +477,7 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
             if (PIPED)
                 accumulate_range_piped<LPR, VEC, VPL, DROPOUT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc);
             else
-                accumulate_range<LPR, VEC, VPL, DROPOUT, NT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc, hot);
+                accumulate_range<LPR, VEC, VPL, DROPOUT, NT, SEG>(k0, k1, indices, vals, b, ldb, lcol, dr, acc, hot, tp);
             store_row<VEC, VPL>(c + (int64_t)r * ldc, add ? add + (int64_t)r * ldadd : nullptr, col, on, acc,
                                 relu != 0, od, r);
         }
@@ -473,14 +495,15 @@ __device__ __forceinline__ void strips_block(int64_t block, int64_t n_strips, co
 //    a cross-lane shuffle), not from memory at claim time.
 //  - HUBS: the first `hub_rows` rows of B (f columns each, row-major) sit in LDS at `hub_lds`; an entry whose
 //    column is below hub_rows takes its row from there instead of from memory.
-template <int LPR, int VEC, int VPL, bool DROPOUT, int kUnroll, bool HUBS = false>
+template <int LPR, int VEC, int VPL, bool DROPOUT, int kUnroll, bool HUBS = false, bool SEG = false>
 __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, const int32_t* __restrict__ strip_row,
                                             const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                             const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                             uint32_t ldb, float* __restrict__ c, int64_t ldc, int relu,
                                             const DropArgs& dr, int split, const float* __restrict__ add,
                                             int64_t ldadd, int64_t nnz, const OutDrop& od,
-                                            const float* hub_lds = nullptr, uint32_t hub_rows = 0) {
+                                            const float* hub_lds = nullptr, uint32_t hub_rows = 0,
+                                            const TwoPart& tp = TwoPart{nullptr, 0, 0}) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
@@ -602,7 +625,7 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
                     // it at this batch's first row of B, which is being fetched anyway, instead of gathering
                     // a row nobody adds -- the path behind the L2 is what a narrow product runs out of
                     const uint32_t cu = (u == 0 || u < rem) ? cidx[u] : cidx[0];
-                    const float* brow = b + (uint64_t)cu * (uint64_t)ldb;
+                    const float* brow = operand_row<SEG>(b, ldb, tp, cu);
                     if (HUBS && cu < hub_rows) {
                         const float* hrow = hub_lds + cu * (uint32_t)f;
 #pragma unroll
@@ -666,14 +689,14 @@ __device__ __forceinline__ void slots_block(int64_t block, int64_t n_strips, con
 }
 
 // one lane group per chunk of a long row -> partial row in the workspace
-template <int LPR, int VEC, int VPL, bool DROPOUT, bool NT = false>
+template <int LPR, int VEC, int VPL, bool DROPOUT, bool NT = false, bool SEG = false>
 __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, const int32_t* __restrict__ chunk_long,
                                              const int32_t* __restrict__ long_row,
                                              const int64_t* __restrict__ long_chunk,
                                              const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                              const float* __restrict__ vals, int64_t f, const float* __restrict__ b,
                                              uint32_t ldb, float* __restrict__ part, int64_t ldp, const DropArgs& dr,
-                                             int chunk_len, uint32_t hot = 0) {
+                                             int chunk_len, uint32_t hot = 0, const TwoPart& tp = TwoPart{nullptr, 0, 0}) {
     constexpr int kGroups = 64 / LPR;
     constexpr int kTile = LPR * VEC * VPL;
     const int lane = threadIdx.x & 63;
@@ -702,7 +725,7 @@ __device__ __forceinline__ void chunks_block(int64_t block, int64_t n_chunks, co
         for (int v = 0; v < VPL; ++v)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[v][e] = 0.0f;
-        accumulate_range<LPR, VEC, VPL, DROPOUT, NT>(k0, k1, indices, vals, b, ldb, lcol, dr, acc, hot);
+        accumulate_range<LPR, VEC, VPL, DROPOUT, NT, SEG>(k0, k1, indices, vals, b, ldb, lcol, dr, acc, hot, tp);
         const OutDrop none = {0, 1.0f, 0, 0, nullptr, 0, 0};   // partial rows are stored as they are
         store_row<VEC, VPL>(part + chunk * ldp, nullptr, col, on, acc, false, none, 0);
     }
@@ -722,7 +745,7 @@ struct PlanView {
 
 // The whole product in one launch: the blocks that sum chunks of long rows come first (they are
 // the longest work items), the strip blocks after them.
-template <int LPR, int VEC, int VPL, bool DROPOUT, int U, bool NT = false, bool HUBS = false>
+template <int LPR, int VEC, int VPL, bool DROPOUT, int U, bool NT = false, bool HUBS = false, bool SEG = false>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const int64_t* __restrict__ indptr,
                                                            const int32_t* __restrict__ indices,
                                                            const float* __restrict__ vals, int64_t f,
@@ -730,17 +753,18 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
                                                            float* __restrict__ c, int64_t ldc,
                                                            float* __restrict__ part, int64_t ldp, int relu,
                                                            DropArgs dr, const float* __restrict__ add,
-                                                           int64_t ldadd, OutDrop od) {
+                                                           int64_t ldadd, OutDrop od, TwoPart tp) {
     if (DROPOUT && dr.stream_offset) dr.key = stream_key(dr.seed, dr.stream_id + *dr.stream_offset);
     if (od.keep_prob < 1.0f && od.stream_offset) od.key = stream_key(od.seed, od.stream_id + *od.stream_offset);
     const int64_t block = blockIdx.x;
     if (block < pv.chunk_blocks)
-        chunks_block<LPR, VEC, VPL, DROPOUT, NT>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk, indptr,
-                                                 indices, vals, f, b, ldb, part, ldp, dr, pv.chunk_len, pv.hot_cols);
+        chunks_block<LPR, VEC, VPL, DROPOUT, NT, SEG>(block, pv.n_chunks, pv.chunk_long, pv.long_row, pv.long_chunk,
+                                                      indptr, indices, vals, f, b, ldb, part, ldp, dr, pv.chunk_len,
+                                                      pv.hot_cols, tp);
     else if (LPR >= 32)
-        strips_block<LPR, VEC, VPL, DROPOUT, (U > kUnroll), NT>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row,
-                                                                indptr, indices, vals, f, b, ldb, c, ldc, relu, dr,
-                                                                pv.split, add, ldadd, od, pv.hot_cols);
+        strips_block<LPR, VEC, VPL, DROPOUT, (U > kUnroll), NT, SEG>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row,
+                                                                     indptr, indices, vals, f, b, ldb, c, ldc, relu, dr,
+                                                                     pv.split, add, ldadd, od, pv.hot_cols, tp);
     else if (HUBS) {
         // stage rows 0 .. lds_hub_rows-1 of B: f is a multiple of 4 and the rows are 16-byte aligned (VEC == 4)
         extern __shared__ float4 hub_stage[];
@@ -756,8 +780,9 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(PlanView pv, const in
                                                      pv.nnz, od, reinterpret_cast<const float*>(hub_stage),
                                                      pv.lds_hub_rows);
     } else
-        slots_block<LPR, VEC, VPL, DROPOUT, U>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr, indices,
-                                            vals, f, b, ldb, c, ldc, relu, dr, pv.split, add, ldadd, pv.nnz, od);
+        slots_block<LPR, VEC, VPL, DROPOUT, U, false, SEG>(block - pv.chunk_blocks, pv.n_strips, pv.strip_row, indptr,
+                                                           indices, vals, f, b, ldb, c, ldc, relu, dr, pv.split, add,
+                                                           ldadd, pv.nnz, od, nullptr, 0, tp);
 }
 
 // partial rows of each long row, added in chunk order; one wave per long row.  Partial rows are
@@ -843,6 +868,7 @@ struct SpmmCall {
     const float* add;
     int64_t ldadd;
     OutDrop od;
+    TwoPart tp;       // n_first == 0: the operand is one matrix
     hipStream_t st;
 };
 
@@ -871,11 +897,11 @@ static int launch_variant(const SpmmCall& a) {
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[0], a.st));
     bool launched = false;
     if constexpr (LPR == 64 && !DROPOUT && U == kUnroll) {
-        if (p->hot_cols > 0 && p->hot_cols < p->n_cols) {
+        if (p->hot_cols > 0 && p->hot_cols < p->n_cols && a.tp.n_first == 0) {
             pv.hot_cols = (uint32_t)p->hot_cols;
             spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U, true><<<(unsigned)grid, kBlock, 0, a.st>>>(
                 pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add,
-                a.ldadd, a.od);
+                a.ldadd, a.od, a.tp);
             launched = true;
         }
     }
@@ -885,19 +911,30 @@ static int launch_variant(const SpmmCall& a) {
         const int64_t fit = kHubLdsBytes / (a.f * (int64_t)sizeof(float));
         const int64_t hubs = std::min<int64_t>(std::min<int64_t>(p->lds_hub_rows, fit), p->n_cols);
         // an empty matrix reads no row of B (b may be null): nothing to stage
-        if (hubs > 0 && p->nnz > 0 && a.b != nullptr && a.f % 4 == 0 && a.f <= LPR * VEC) {
+        if (hubs > 0 && p->nnz > 0 && a.b != nullptr && a.tp.n_first == 0 && a.f % 4 == 0 && a.f <= LPR * VEC) {
             pv.lds_hub_rows = (uint32_t)hubs;
             const size_t lds_bytes = (size_t)hubs * (size_t)a.f * sizeof(float);
             spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U, false, true><<<(unsigned)grid, kBlock, lds_bytes, a.st>>>(
                 pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add,
-                a.ldadd, a.od);
+                a.ldadd, a.od, a.tp);
             launched = true;
         }
     }
+    if constexpr (VEC == 4 && !DROPOUT && U == kUnroll) {
+        if (!launched && a.tp.n_first > 0) {     // two-part operand (wide and narrow instances of large matrices)
+            spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U, false, false, true><<<(unsigned)grid, kBlock, 0, a.st>>>(
+                pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add,
+                a.ldadd, a.od, a.tp);
+            launched = true;
+        }
+    }
+    if (!launched && a.tp.n_first > 0)
+        return fail(GCN_ERR_BAD_ARG, "this product has no two-part form (it needs 16-byte aligned rows, a width that is "
+                                     "a multiple of 4 and a matrix of at least 2M entries): pass the operand as one matrix");
     if (!launched)
         spmm_rows_kernel<LPR, VEC, VPL, DROPOUT, U><<<(unsigned)grid, kBlock, 0, a.st>>>(
             pv, a.indptr, a.indices, a.vals, a.f, a.b, a.ldb, a.c, a.ldc, a.part, a.ldp, a.relu, a.dr, a.add,
-            a.ldadd, a.od);
+            a.ldadd, a.od, a.tp);
     GCN_LAUNCH_CHECK();
     if (p->timing) GCN_HIP_TRY(hipEventRecord(p->ev[1], a.st));
     if (lt.n_chunks > 0) {
@@ -944,7 +981,7 @@ template <bool DROPOUT>
 static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
                       int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc, int flags, void* workspace,
                       size_t workspace_bytes, DropArgs dr, void* stream, const float* add = nullptr,
-                      int64_t ldadd = 0, const OutDrop* od = nullptr) {
+                      int64_t ldadd = 0, const OutDrop* od = nullptr, const TwoPart* first_part = nullptr) {
     if (!plan) return fail(GCN_ERR_BAD_ARG, "plan is null");
     if (add && ldadd < f) return fail(GCN_ERR_BAD_ARG, "bad addend leading dimension %lld", (long long)ldadd);
     if (f < 0 || ldb < f || ldc < f || ldb > INT32_MAX || f > INT32_MAX - 1024)
@@ -972,6 +1009,13 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
     a.ldadd = ldadd;
     a.od = od ? out_drop_ready(*od) : OutDrop{0, 1.0f, 0, 0, nullptr, 0, 0};
     a.st = (hipStream_t)stream;
+    a.tp = TwoPart{nullptr, 0, 0};
+    if (first_part && first_part->n_first > 0) {
+        // rows [0, n_first) at first_part->first; the caller's b holds the rows from n_first on: move it back so
+        // that both parts are addressed by the operand's own row numbers
+        a.tp = *first_part;
+        a.b = (const float*)((uintptr_t)b - (uintptr_t)first_part->n_first * (uintptr_t)ldb * sizeof(float));
+    }
     const int64_t max_chunks = std::max(plan->table[0].n_chunks, plan->table[1].n_chunks);
     if (max_chunks > 0) {
         const size_t need = (size_t)max_chunks * (size_t)a.ldp * sizeof(float);
@@ -981,7 +1025,8 @@ static int spmm_entry(const gcn_spmm_plan* plan, const int64_t* indptr, const in
         a.part = (float*)workspace;
     }
     const bool vec4 = (f % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(b) && aligned16(c) &&
-                      (!add || ((ldadd % 4 == 0) && aligned16(add)));
+                      (!add || ((ldadd % 4 == 0) && aligned16(add))) &&
+                      (a.tp.n_first == 0 || ((a.tp.ld_first % 4 == 0) && aligned16(a.tp.first)));
     return vec4 ? launch_by_width<4, DROPOUT>(a) : launch_by_width<1, DROPOUT>(a);
 }
 
@@ -1236,6 +1281,33 @@ int gcn_spmm_csr_f32_noalloc(const gcn_spmm_plan* plan, const int64_t* indptr, c
     DropArgs dr = {nullptr, 0, 1.0f, 1.0f};
     return spmm_entry<false>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, ptr, need ? kScratchBytes : 0, dr,
                              stream);
+}
+
+int gcn_spmm_csr_two_part_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                              const float* vals, int64_t f, const float* b_first, int64_t ld_first, int64_t n_first,
+                              const float* b_rest, int64_t ld_rest, float* c, int64_t ldc, int flags, float keep_prob,
+                              uint64_t seed, uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset,
+                              int64_t pitch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!plan) return fail(GCN_ERR_BAD_ARG, "plan is null");
+    if (n_first < 0 || n_first > plan->n_cols || ld_first < f || ld_first > INT32_MAX)
+        return fail(GCN_ERR_BAD_ARG, "bad first part: %lld rows of pitch %lld for a %lld-column matrix, width %lld",
+                    (long long)n_first, (long long)ld_first, (long long)plan->n_cols, (long long)f);
+    if (n_first > 0 && !b_first && plan->nnz > 0) return fail(GCN_ERR_BAD_ARG, "null dense pointer");
+    if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
+    DropArgs dr = {nullptr, 0, 1.0f, 1.0f};
+    OutDrop od = {0, 1.0f, 0, 0, nullptr, 0, 0};
+    if (keep_prob < 1.0f) {
+        if (index_offset < 0 || pitch < f)
+            return fail(GCN_ERR_BAD_ARG, "bad decision layout: index_offset=%lld pitch=%lld for %lld columns",
+                        (long long)index_offset, (long long)pitch, (long long)f);
+        od = OutDrop{stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset, seed, stream_id};
+    }
+    const TwoPart tp = {b_first, (uint32_t)ld_first, (uint32_t)n_first};
+    // a matrix whose every column lies in the first part never reads b_rest: any valid pointer stands in for it
+    const float* rest = (n_first == plan->n_cols && !b_rest) ? b_first : b_rest;
+    return spmm_entry<false>(plan, indptr, indices, vals, f, rest, n_first == plan->n_cols && !b_rest ? ld_first : ld_rest,
+                             c, ldc, flags, workspace, workspace_bytes, dr, stream, nullptr, 0,
+                             keep_prob < 1.0f ? &od : nullptr, &tp);
 }
 
 int gcn_spmm_csr_add_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,

@@ -175,19 +175,20 @@ class AllGatherSpmm(object):
 class HaloPlan(object):
     """Which rows of a row-sharded dense matrix every rank needs from every other rank.
 
-    Set-up (integer work, once per graph): the distinct columns of the local shard are sorted --
-    which groups them by owner rank, since owners hold contiguous blocks -- the shard's column
-    indices are renumbered to positions in that list (the order of the entries inside a row does
-    not change, so sums are bit-identical), and the ranks exchange their request lists.
-    ``exchange(b_local)`` then gathers the requested local rows and moves them with one
-    ``all_to_all_single``.  On a skewed graph most vertices have few neighbours, so a shard
-    references a fraction of the columns (72 / 52 / 37 % at 2 / 4 / 8 ranks on the scale-24 R-MAT) and
-    the exchange moves that fraction of what an all-gather moves."""
+    Set-up (integer work, once per graph): the distinct columns of the local shard that belong to OTHER
+    ranks are sorted -- which groups them by owner rank, since owners hold contiguous blocks -- and the ranks
+    exchange their request lists.  The operand of the local product then has two parts: the rank's own
+    rows, read where they lie, and the received rows, in that sorted order; the shard's column indices are
+    renumbered to positions in it (own rows first; the order of the entries inside a row does not change,
+    so sums are bit-identical).  ``exchange(b_local)`` gathers the rows the others requested and moves them
+    with one ``all_to_all_single``; the own rows are never packed or copied.  On a skewed graph most
+    vertices have few neighbours, so a shard references a fraction of the columns (72 / 52 / 37 % at 2 / 4
+    / 8 ranks on the scale-24 R-MAT), of which only the other ranks' (22 / 27 / 24 % of N) cross a link."""
 
     def __init__(self, shard, group=None, csr_factory=None, operand_rows=None):
         """``operand_rows`` (ascending local row numbers, int64): the dense operand every rank passes to
-        ``exchange`` holds only these rows of its block, in this order (every requested row must be among
-        them)."""
+        ``exchange`` holds only these rows of its block, in this order (every row of the block that anyone
+        references must be among them)."""
         self.shard, self.group = shard, group
         local = shard.local
         dev = local.device
@@ -196,18 +197,33 @@ class HaloPlan(object):
         if shard.n_cols % world != 0:
             raise ValueError('n_cols=%d is not a multiple of the world size %d' % (shard.n_cols, world))
         self._collective = world > 1 or (dist.is_initialized() and dist.get_world_size(group) == 1)
+        self._buffers, self._side = {}, None                         # stream of exchange_ranges: made on first use
         if not self._collective and operand_rows is None:
-            # one process, no communicator: the operand holds every column's row, B is its own halo
-            self.compact, self.n_needed, self._identity, self._buffers = local, shard.n_cols, True, {}
-            self._side = None
-            self.recv_splits = self.send_splits = [shard.n_cols]
+            # one process, no communicator: the operand holds every column's row, B is the whole operand
+            self.compact, self.n_first, self.n_remote, self._identity = local, shard.n_cols, 0, True
+            self.recv_splits = self.send_splits = [0]
             return
+        r0 = shard.rank * per
         cols = local.indices.to(torch.int64)
-        needed = torch.unique(cols)                                  # sorted: grouped by owner
-        new_cols = torch.searchsorted(needed, cols).to(torch.int32)
-        owner = torch.div(needed, per, rounding_mode='floor')
+        mine = (cols >= r0) & (cols < r0 + per)
+        remote = torch.unique(cols[~mine])                           # sorted: grouped by owner
+        # own rows: where they lie in the operand the caller passes (its whole block, or operand_rows of it)
+        if operand_rows is not None:
+            position = torch.full((per,), -1, dtype=torch.int64, device=dev)
+            position[operand_rows] = torch.arange(operand_rows.numel(), dtype=torch.int64, device=dev)
+            self.n_first = int(operand_rows.numel())
+            own_cols = position[(cols - r0).clamp_(0, per - 1)]
+            if bool((own_cols[mine] < 0).any()):
+                raise ValueError('a referenced row of the own block is not among operand_rows')
+        else:
+            position = None
+            self.n_first = per
+            own_cols = cols - r0
+        new_cols = torch.where(mine, own_cols, torch.searchsorted(remote, cols) + self.n_first).to(torch.int32)
+        del own_cols, cols, mine
+        owner = torch.div(remote, per, rounding_mode='floor')
         self.recv_counts = torch.bincount(owner, minlength=world).to(torch.int64)
-        request = (needed - owner * per).contiguous()                # row offsets inside the owner's block
+        request = (remote - owner * per).contiguous()                # row offsets inside the owner's block
         # tell every owner which of its rows this rank wants
         self.send_counts = torch.empty(world, dtype=torch.int64, device=dev)
         # a 1-rank process group still goes through the collectives (same code path as N ranks)
@@ -222,18 +238,25 @@ class HaloPlan(object):
             all_to_all_rows(self.send_rows, request, self.send_splits, self.recv_splits, group=group)
         else:
             self.send_rows.copy_(request)
-        if operand_rows is not None:                                 # row numbers -> positions in the operand
-            position = torch.full((per,), -1, dtype=torch.int64, device=dev)
-            position[operand_rows] = torch.arange(operand_rows.numel(), dtype=torch.int64, device=dev)
+        if position is not None:                                     # row numbers -> positions in the operand
             self.send_rows = position[self.send_rows]
             if self.send_rows.numel() and int(self.send_rows.min()) < 0:
                 raise ValueError('a requested row is not among operand_rows')
+        self.n_remote = int(remote.numel())
         make = csr_factory or sparse.DeviceCSR
-        self.compact = make(local.n_rows, int(needed.numel()), local.indptr, new_cols, local.values)
-        self.n_needed = int(needed.numel())
+        self.compact = make(local.n_rows, self.n_first + self.n_remote, local.indptr, new_cols, local.values)
         self._identity = False
-        self._buffers = {}
-        self._side = None                                            # stream of exchange_ranges, made on first use
+
+    def multiply(self, b_local, received, relu=False, out=None, spmm=None, **extra):
+        """``compact . [b_local; received]`` without stacking the two parts (``sparse.spmm(first=...)``); a
+        multiply function of the caller's (tests inject the CPU oracle) gets the stacked operand."""
+        if self._identity:
+            return (spmm or sparse.spmm)(self.compact, b_local, relu=relu, out=out, **extra)
+        if b_local.shape[0] != self.n_first:
+            raise ValueError('the operand has %d rows, the plan expects %d' % (b_local.shape[0], self.n_first))
+        if spmm is None or spmm is sparse.spmm:
+            return sparse.spmm(self.compact, received, relu=relu, out=out, first=b_local, **extra)
+        return spmm(self.compact, torch.cat([b_local, received]), relu=relu, out=out, **extra)
 
     def drop_buffers(self, keep_widths=()):
         """Free the cached send / receive buffers of every width not in ``keep_widths``."""
@@ -244,7 +267,7 @@ class HaloPlan(object):
         bufs = self._buffers.get((f, slot))
         if bufs is None:
             bufs = (torch.empty((self.send_rows.numel(), f), dtype=torch.float32, device=device),
-                    torch.empty((self.n_needed, f), dtype=torch.float32, device=device))
+                    torch.empty((self.n_remote, f), dtype=torch.float32, device=device))
             self._buffers[(f, slot)] = bufs
         return bufs
 
@@ -261,7 +284,7 @@ class HaloPlan(object):
         packing nor a collective that had to wait for an earlier product.  Every range has buffers of its
         own (together: one full-width pair)."""
         if self._identity:
-            return [(b_local[:, lo:hi], _Done) for lo, hi in ranges]
+            return [(None, _Done) for lo, hi in ranges]
         staged = self._collective and _through_host(b_local, self.group)
         if not b_local.is_cuda or staged:
             # host tensors, and the gloo rehearsal that stages device tensors through the host: in order
@@ -289,11 +312,11 @@ class HaloPlan(object):
         return out
 
     def exchange(self, b_local, slot=0):
-        """Rows of the global matrix this rank's shard references, [n_needed x f], in column order, moved
-        on the caller's stream (the exchange a product of one column range waits for as a whole).
+        """The rows of the other ranks' blocks this rank's shard references, [n_remote x f], grouped by owner,
+        moved on the caller's stream (the exchange a product of one column range waits for as a whole).
         ``slot`` picks one of the cached buffer pairs of this width."""
-        if self._identity:                      # one rank and every column referenced: B itself
-            return b_local
+        if self._identity:                      # one process: nothing to receive
+            return None
         send_buf, b_halo = self._buffers_for(b_local.shape[1], slot, b_local.device)
         if b_local.is_cuda:
             sparse.gather_rows(b_local, self.send_rows, send_buf)      # column slices are read in place
@@ -366,7 +389,7 @@ class HaloSpmm(object):
         self._spmm = spmm or sparse.spmm
         self.plan = plan or HaloPlan(shard, group=group, csr_factory=csr_factory)
         self.compact = self.plan.compact
-        self.n_needed = self.plan.n_needed
+        self.n_remote = self.plan.n_remote
         self.recv_splits = self.plan.recv_splits
         self.ranges = column_chunks(f, chunks)
         self.c_local = torch.empty((shard.local.n_rows, f), dtype=torch.float32, device=shard.local.device)
@@ -429,7 +452,6 @@ def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None, out_dro
     and the product of a range starts when its rows have arrived, so only the first range's exchange is exposed.
     ``out_dropout`` (sparse.OutDropout over the full width, index_offset = first local row * width):
     the output is stored already dropped."""
-    spmm = spmm or sparse.spmm
     f = b_local.shape[1]
     ranges = ranges or [(0, f)]
     extra = {}
@@ -439,10 +461,10 @@ def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None, out_dro
     if len(ranges) == 1:
         if out_dropout is not None:
             extra['out_dropout'] = out_dropout
-        return spmm(plan.compact, plan.exchange(b_local), relu=relu, out=out, **extra)
+        return plan.multiply(b_local, plan.exchange(b_local), relu=relu, out=out, spmm=spmm, **extra)
     for (c0, c1), (rows, work) in zip(ranges, plan.exchange_ranges(b_local, ranges)):
         work.wait()
         if out_dropout is not None:
             extra['out_dropout'] = out_dropout.columns(c0)
-        spmm(plan.compact, rows, relu=relu, out=out[:, c0:c1], wide_split=f >= 128, **extra)
+        plan.multiply(b_local[:, c0:c1], rows, relu=relu, out=out[:, c0:c1], spmm=spmm, wide_split=f >= 128, **extra)
     return out

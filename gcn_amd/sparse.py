@@ -428,14 +428,41 @@ class OutDropout(object):
         return OutDropout(self.keep_prob, self.seed, self.stream_id, self.index_offset + c0, self.pitch, self.row_ids)
 
 
-def spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None):
+def _two_part_form(a, f, first, b, out):
+    """True when the product kernels can read the operand [first; b] in place: 128-bit rows in both parts and
+    a matrix large enough for the strip instances that have the two-part form."""
+    if f % 4 or a.nnz + 4 * a.n_rows < SMALL_MATRIX_WORK:
+        return False
+    for t in (first, b, out):
+        if t is not None and t.numel() and (t.data_ptr() % 16 or _ld(t) % 4):
+            return False
+    return True
+
+
+def spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None, first=None):
     """``a @ b`` for a DeviceCSR ``a`` and dense float32 ``b`` (optionally with ReLU fused).
     ``wide_split`` cuts long rows as a wide product does, whatever the width of ``b``: use it when
     ``b`` is a range of the columns of a wider operand and the bits must match the full product.
-    ``out_dropout`` (an OutDropout): the result is written already dropped, after the ReLU."""
+    ``out_dropout`` (an OutDropout): the result is written already dropped, after the ReLU.
+    ``first``: the operand is ``[first; b]`` -- the rows of ``first`` followed by those of ``b`` (which may be
+    None or empty) -- and is read in place, without stacking the two (a stacked copy is made only for
+    layouts the kernels' two-part form does not take)."""
+    if first is not None:
+        _require_cuda(first)
+        first = _rowmajor(first)
+        if b is None:
+            b = first.new_empty((0, first.shape[1]))
+        _require_cuda(b)
+        b = _rowmajor(b)
+        if first.shape[0] + b.shape[0] != a.n_cols or first.shape[1] != b.shape[1]:
+            raise ValueError('shape mismatch: %s @ [%s; %s]' % (a.shape, tuple(first.shape), tuple(b.shape)))
+        if first.shape[0] == 0:
+            first = None
+        elif not _two_part_form(a, b.shape[1], first, b, out):
+            b, first = torch.cat([first, b]), None
     _require_cuda(b)
     b = _rowmajor(b)
-    if b.shape[0] != a.n_cols:
+    if first is None and b.shape[0] != a.n_cols:
         raise ValueError('shape mismatch: %s @ %s' % (a.shape, tuple(b.shape)))
     f = b.shape[1]
     if out is None:
@@ -444,6 +471,17 @@ def spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None):
         _check_out(out, a.n_rows, f)
     ws, ws_bytes = a.plan.workspace(f, b.device)
     flags = (_lib.GCN_RELU if relu else 0) | (_lib.GCN_SPLIT_WIDE if wide_split else 0)
+    if first is not None:
+        d = out_dropout if (out_dropout is not None and out_dropout.keep_prob < 1.0) else None
+        if d is not None and d.row_ids is not None:
+            raise ValueError('row_ids apply to dense products only')
+        rest = b if b.shape[0] else None
+        _lib.call('gcn_spmm_csr_two_part_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(first),
+                  _ld(first), first.shape[0], _p(rest), _ld(b) if rest is not None else f, _p(out), _ld(out), flags,
+                  d.keep_prob if d else 1.0, d.seed if d else 0, d.stream_id if d else 0,
+                  _p(_stream_offset) if d else ctypes.c_void_p(0), d.index_offset if d else 0,
+                  (f if d.pitch is None else int(d.pitch)) if d else f, _p(ws), ws_bytes, _stream())
+        return out
     if out_dropout is not None and out_dropout.keep_prob < 1.0:
         d = out_dropout
         if d.row_ids is not None:

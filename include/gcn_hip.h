@@ -250,6 +250,21 @@ int gcn_spmm_csr_f32_noalloc(const gcn_spmm_plan* plan, const int64_t* indptr, c
                              const float* vals, int64_t f, const float* b, int64_t ldb, float* c, int64_t ldc,
                              int flags, void* stream);
 
+/* gcn_spmm_csr_f32 (optionally with the store dropout of gcn_spmm_csr_out_dropout_f32: keep_prob < 1) for a
+ * dense operand stored in TWO parts: its rows [0, n_first) at b_first (row pitch ld_first), the rows from n_first
+ * on at b_rest (row pitch ld_rest; b_rest[0] is row n_first).  The rank of a row-partitioned product reads its own
+ * block of the per-layer matrix (`pre_sup`, gcn/layers.py:198-202) where it lies and only the rows received from
+ * the other ranks from the exchange buffer, so the own rows are never packed or copied; the single-process reference
+ * has no counterpart.  Same additions in the same order as the product on the stacked operand: the same bits.
+ * Needs 16-byte aligned rows in both parts, f a multiple of 4 and a plan whose matrix has at least ~2M entries
+ * (the instances for small matrices have no two-part form): otherwise GCN_ERR_BAD_ARG, and the caller stacks the
+ * operand. */
+int gcn_spmm_csr_two_part_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                              const float* vals, int64_t f, const float* b_first, int64_t ld_first, int64_t n_first,
+                              const float* b_rest, int64_t ld_rest, float* c, int64_t ldc, int flags, float keep_prob,
+                              uint64_t seed, uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset,
+                              int64_t pitch, void* workspace, size_t workspace_bytes, void* stream);
+
 /* C = A . B + D: one smoothing / propagation step with the residual added in the epilogue
  * (`new_feature = adj * new_feature + features`, gcn/utils.py:568-569; float32 here).  D is a
  * dense [n_rows x f] matrix; GCN_RELU applies after the addition. */

@@ -72,8 +72,10 @@ def _worker(rank, world, port, result_dir):
         halo = gdist.HaloSpmm(shard, f, spmm=_oracle_spmm, csr_factory=_HostCSR)
         c_halo = halo(torch.from_numpy(b[r0:r1].copy()), relu=True)
         assert torch.equal(c_halo, c_local)
-        assert halo.n_needed <= n_pad and sum(halo.recv_splits) == halo.n_needed
-        np.save(os.path.join(result_dir, 'needed_%d.npy' % rank), np.array([halo.n_needed]))
+        # own rows are read in place; only other ranks' rows are received (none from oneself)
+        assert sum(halo.recv_splits) == halo.n_remote and halo.recv_splits[rank] == 0
+        assert halo.plan.n_first == r1 - r0 and halo.compact.n_cols == halo.plan.n_first + halo.n_remote
+        np.save(os.path.join(result_dir, 'needed_%d.npy' % rank), np.array([halo.n_remote]))
         # pipelined over ranges of feature columns (uneven ranges, two buffer slots): still the same bits
         piped = gdist.HaloSpmm(shard, f, spmm=_oracle_spmm, plan=halo.plan, chunks=3)
         assert piped.ranges == [(0, 4), (4, 8), (8, 16)]

@@ -174,13 +174,13 @@ def test_last_of_eight_row_blocks_and_its_compact_operand_product(graph26):
     needed = torch.unique(indices.to(torch.int64))
     assert 0.2 * n < needed.numel() < 0.6 * n         # a skewed graph: a block references a fraction of the rows
     plan = gdist.HaloPlan(shard, operand_rows=needed)
-    assert plan.n_needed == needed.numel() and plan.compact.n_cols == needed.numel()
+    assert plan.n_first == needed.numel() and plan.n_remote == 0 and plan.compact.n_cols == needed.numel()
     for f in (8, 128):
         b = sparse.synthetic_dense(n, f, seed=7)
         c_rows = sparse.spmm(a, b)[r0:r1].clone()
         operand = b[needed].contiguous()
         del b
-        got = sparse.spmm(plan.compact, plan.exchange(operand))
+        got = plan.multiply(operand, plan.exchange(operand))
         assert torch.equal(got, c_rows)
         del got, c_rows, operand
         plan.drop_buffers()

@@ -214,3 +214,40 @@ def test_lds_hub_rows_on_an_empty_matrix():
               ctypes.c_void_p(out.data_ptr()), f, 0, None, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert bool((out == 0).all())
+
+
+@pytest.mark.parametrize('f', [4, 16, 32, 64, 128, 256, 512, 640])
+def test_operand_in_two_parts_gives_the_bits_of_the_stacked_operand(big_hat, f):
+    """gcn_spmm_csr_two_part_f32: the dense operand as [first; rest], read in place -- what a rank of the
+    row-partitioned product does with its own rows and the rows it received.  Every width class of the
+    large-matrix kernels, with the ReLU and the store dropout, parts of different row pitch, an empty second
+    part, and the layouts the two-part form does not take (which the wrapper stacks)."""
+    import torch
+    from gcn_amd import sparse
+    n, a, ip, ix, v = big_hat
+    b = sparse.synthetic_dense(n, f, seed=41)
+    whole = sparse.spmm(a, b)
+    whole_relu = sparse.spmm(a, b, relu=True)
+    for n_first in (1, n // 3, n - 5, n):
+        first, rest = b[:n_first].clone(), b[n_first:].clone()
+        assert torch.equal(sparse.spmm(a, rest, first=first), whole)
+        assert torch.equal(sparse.spmm(a, rest if n_first < n else None, first=first, relu=True), whole_relu)
+    n_first = n // 3
+    # parts that are column ranges of wider matrices (row pitch > f), output a column range too
+    wide_first = torch.zeros((n_first, f + 8), device='cuda')
+    wide_first[:, 4:4 + f] = b[:n_first]
+    wide_rest = torch.zeros((n - n_first, f + 12), device='cuda')
+    wide_rest[:, 8:8 + f] = b[n_first:]
+    out = torch.full((n, f + 4), -2.0, device='cuda')
+    sparse.spmm(a, wide_rest[:, 8:8 + f], first=wide_first[:, 4:4 + f], out=out[:, 4:])
+    assert torch.equal(out[:, 4:], whole) and bool((out[:, :4] == -2.0).all())
+    drop = sparse.OutDropout(0.5, 17, 3, index_offset=8 * f, pitch=f)
+    assert torch.equal(sparse.spmm(a, b[n_first:], first=b[:n_first], relu=True, out_dropout=drop),
+                       sparse.spmm(a, b, relu=True, out_dropout=drop))
+    assert torch.equal(sparse.spmm(a, b[n_first:], first=b[:n_first], wide_split=True), sparse.spmm(a, b, wide_split=True))
+    # a layout without 128-bit rows: the wrapper stacks the parts
+    odd = torch.zeros((n_first, f + 1), device='cuda')
+    odd[:, 1:] = b[:n_first]
+    assert torch.equal(sparse.spmm(a, b[n_first:], first=odd[:, 1:]), whole)
+    with pytest.raises(ValueError, match='shape mismatch'):
+        sparse.spmm(a, b[n_first + 1:], first=b[:n_first])

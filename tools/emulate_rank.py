@@ -4,7 +4,8 @@ Rank 0's shard of the scale-24 R-MAT graph for 2, 4 and 8 ranks goes through ``d
 plan whose exchange is a device copy of the bytes the rank would receive (``HaloPlan`` without a
 communicator): packing on the plan's side stream, the copy standing in for the link transfer (it loads
 HBM as sending plus receiving does, it does not take the time a link takes), the products of the column
-ranges on the caller's stream.  Measured per candidate split: the products alone, the whole pipeline, the
+ranges on the caller's stream, reading the rank's own rows of B in place and the received rows from the
+exchange buffer.  Measured per candidate split: the products alone, the whole pipeline, the
 packing and the copy of the first range.  Modelled: the step time with the first range's copy replaced
 by its transfer time over xGMI at the nominal 153 GB/s per link (P - 1 links in use), and the
 strong-scaling efficiency E(P) = T_1 / (P T_P) against the one-GPU product measured in the same run.
@@ -41,21 +42,24 @@ def timed(fn, reps=8):
 
 
 def stand_in_plan(shard, per):
-    """A HaloPlan of one process standing for one rank of ``world``: the compact matrix and the row count of
-    the real plan; the rows it packs are random rows of its own block, as many as the plan references, and
-    the "exchange" copies them into the receive buffer."""
+    """A HaloPlan of one process standing for one rank of ``world``: the compact matrix (own rows first, then
+    the rows of other blocks the shard references) and the row counts of the real plan; the rows it packs are
+    random rows of its own block, as many as it receives, and the "exchange" copies them into the receive
+    buffer."""
     local = shard.local
+    r0 = shard.row_begin
     cols = local.indices.to(torch.int64)
-    needed = torch.unique(cols)
-    new_cols = torch.searchsorted(needed, cols).to(torch.int32)
+    mine = (cols >= r0) & (cols < r0 + per)
+    remote = torch.unique(cols[~mine])
+    new_cols = torch.where(mine, cols - r0, torch.searchsorted(remote, cols) + per).to(torch.int32)
     plan = gdist.HaloPlan.__new__(gdist.HaloPlan)
     plan.shard, plan.group = shard, None
-    plan.compact = sparse.DeviceCSR(local.n_rows, int(needed.numel()), local.indptr, new_cols, local.values)
-    plan.n_needed = int(needed.numel())
+    plan.n_first, plan.n_remote = per, int(remote.numel())
+    plan.compact = sparse.DeviceCSR(local.n_rows, per + plan.n_remote, local.indptr, new_cols, local.values)
     plan._identity, plan._collective, plan._buffers, plan._side = False, False, {}, None
-    own = int(((needed >= shard.row_begin) & (needed < shard.row_end)).sum())
-    plan.send_rows = torch.randint(0, per, (plan.n_needed,), device=local.device)
-    return plan, own
+    plan.send_rows = torch.randint(0, per, (plan.n_remote,), device=local.device)
+    referenced_own = int(torch.unique(cols[mine]).numel())
+    return plan, referenced_own
 
 
 def main():
@@ -83,12 +87,12 @@ def main():
         plan, own = stand_in_plan(shard, per)
         b_local = b[:per]
         out = torch.empty((per, f), device='cuda')
-        recv_rows = plan.n_needed - own                    # rows that come over the links
+        recv_rows = plan.n_remote                          # rows that come over the links
         links = world - 1
-        halo = torch.empty((plan.n_needed, f), device='cuda').copy_(b[:plan.n_needed])
-        t_full = timed(lambda: sparse.spmm(plan.compact, halo, out=out))
-        entry = {'world': world, 'rows_per_rank': per, 'referenced_rows': plan.n_needed,
-                 'referenced_share_of_n': plan.n_needed / n, 'rows_over_links': recv_rows,
+        halo = torch.empty((plan.n_remote, f), device='cuda').copy_(b[per:per + plan.n_remote])
+        t_full = timed(lambda: sparse.spmm(plan.compact, halo, out=out, first=b_local))
+        entry = {'world': world, 'rows_per_rank': per, 'referenced_rows': own + plan.n_remote,
+                 'referenced_share_of_n': (own + plan.n_remote) / n, 'rows_over_links': recv_rows,
                  'received_gb_per_product': recv_rows * f * 4 / 1e9, 'local_product_full_width_ms': t_full,
                  'link_total_ms': recv_rows * f * 4 / (links * LINK_GBPS * 1e9) * 1e3, 'splits': []}
         for shares in gdist.HaloSpmm.CANDIDATES:
@@ -97,7 +101,8 @@ def main():
 
             def products_alone():
                 for lo, hi in ranges:
-                    sparse.spmm(plan.compact, halo[:, lo:hi], out=out[:, lo:hi], wide_split=f >= 128)
+                    sparse.spmm(plan.compact, halo[:, lo:hi], out=out[:, lo:hi], wide_split=f >= 128,
+                                first=b_local[:, lo:hi])
 
             def pipeline():
                 gdist.halo_product(plan, b_local, out, False, ranges)
@@ -110,7 +115,7 @@ def main():
             t_copy0 = timed(lambda: recv0.copy_(send0))
             link0 = recv_rows * w0 * 4 / (links * LINK_GBPS * 1e9) * 1e3
             if t_pipe is None:                 # one range: packing, the whole exchange, then the product
-                t_pipe = timed(lambda: sparse.spmm(plan.compact, plan.exchange(b_local), out=out))
+                t_pipe = timed(lambda: plan.multiply(b_local, plan.exchange(b_local), out=out))
             modelled = t_pipe - t_copy0 + link0
             entry['splits'].append({'widths': widths, 'products_alone_ms': t_products, 'pipeline_ms': t_pipe,
                                     'pack_first_range_ms': t_pack0, 'copy_first_range_ms': t_copy0,
@@ -125,7 +130,7 @@ def main():
         entry['best'] = best
         report['worlds'].append(entry)
         print('world %d: references %.1f%% of N, full-width local product %.2f ms, links busy %.2f ms per product; '
-              'best split %s: E(%d) = %.3f' % (world, 100.0 * plan.n_needed / n, t_full, entry['link_total_ms'],
+              'best split %s: E(%d) = %.3f' % (world, 100.0 * (own + plan.n_remote) / n, t_full, entry['link_total_ms'],
                                                best['widths'], world, best['modelled_efficiency']), flush=True)
         del shard, plan, halo, out, b_local
         torch.cuda.empty_cache()
