@@ -5,10 +5,12 @@ plan whose exchange is a device copy of the bytes the rank would receive (``Halo
 communicator): packing on the plan's side stream, the copy standing in for the link transfer (it loads
 HBM as sending plus receiving does, it does not take the time a link takes), the products of the column
 ranges on the caller's stream, reading the rank's own rows of B in place and the received rows from the
-exchange buffer.  Measured per candidate split: the products alone, the whole pipeline, the
-packing and the copy of the first range.  Modelled: the step time with the first range's copy replaced
-by its transfer time over xGMI at the nominal 153 GB/s per link (P - 1 links in use), and the
-strong-scaling efficiency E(P) = T_1 / (P T_P) against the one-GPU product measured in the same run.
+exchange buffer.  Measured per candidate split: the product of every range alone, the whole pipeline, the
+packing and the copy of every range.  Modelled: the timeline of a step in which range i crosses the links
+after range i - 1 at the nominal 153 GB/s per link (P - 1 links in use) and its product starts once it
+has arrived and the product before it has finished -- the products slowed down by the factor the measured
+pipeline shows them to lose beside the exchange traffic -- and the strong-scaling efficiency
+E(P) = T_1 / (P T_P) against the one-GPU product measured in the same run.
 
     python tools/emulate_rank.py [--scale 24] [--features 256] [--out gpurun_out/r3/rank_emulation.json]
 """
@@ -99,31 +101,43 @@ def main():
             ranges = gdist.column_shares(f, shares)
             widths = [hi - lo for lo, hi in ranges]
 
-            def products_alone():
-                for lo, hi in ranges:
-                    sparse.spmm(plan.compact, halo[:, lo:hi], out=out[:, lo:hi], wide_split=f >= 128,
-                                first=b_local[:, lo:hi])
+            def product_of(i):
+                lo, hi = ranges[i]
+                return lambda: sparse.spmm(plan.compact, halo[:, lo:hi], out=out[:, lo:hi], wide_split=f >= 128,
+                                           first=b_local[:, lo:hi])
 
             def pipeline():
-                gdist.halo_product(plan, b_local, out, False, ranges)
+                if len(ranges) > 1:
+                    gdist.halo_product(plan, b_local, out, False, ranges)
+                else:                              # one range: packing, the whole exchange, then the product
+                    plan.multiply(b_local, plan.exchange(b_local), out=out)
 
-            w0 = widths[0]
-            send0, recv0 = plan._buffers_for(w0, 0, b_local.device)
-            t_products = timed(products_alone)
-            t_pipe = timed(pipeline) if len(ranges) > 1 else None
-            t_pack0 = timed(lambda: sparse.gather_rows(b_local[:, :w0], plan.send_rows, send0))
-            t_copy0 = timed(lambda: recv0.copy_(send0))
-            link0 = recv_rows * w0 * 4 / (links * LINK_GBPS * 1e9) * 1e3
-            if t_pipe is None:                 # one range: packing, the whole exchange, then the product
-                t_pipe = timed(lambda: plan.multiply(b_local, plan.exchange(b_local), out=out))
-            modelled = t_pipe - t_copy0 + link0
-            entry['splits'].append({'widths': widths, 'products_alone_ms': t_products, 'pipeline_ms': t_pipe,
-                                    'pack_first_range_ms': t_pack0, 'copy_first_range_ms': t_copy0,
-                                    'link_first_range_ms': link0, 'modelled_step_ms': modelled,
+            t_each = [timed(product_of(i)) for i in range(len(ranges))]
+            t_pipe = timed(pipeline)
+            bufs = [plan._buffers_for(w, i, b_local.device) for i, w in enumerate(widths)]
+            t_pack = [timed(lambda i=i: sparse.gather_rows(b_local[:, ranges[i][0]:ranges[i][1]], plan.send_rows, bufs[i][0]))
+                      for i in range(len(ranges))]
+            t_copy = [timed(lambda i=i: bufs[i][1].copy_(bufs[i][0])) for i in range(len(ranges))]
+            link = [recv_rows * w * 4 / (links * LINK_GBPS * 1e9) * 1e3 for w in widths]
+            # How much the products slow down while the exchange traffic shares the memory system with them:
+            # the measured pipeline against its own critical path (first pack and copy, then the products).
+            slowdown = max(1.0, (t_pipe - t_pack[0] - t_copy[0]) / sum(t_each))
+            # Timeline of a step on P GPUs: range i is packed (packing of range i + 1 overlaps the transfer of
+            # range i), crosses the links one range after the other, and its product starts when it has arrived
+            # and the product before it has finished.
+            sent, done, arrivals = t_pack[0], 0.0, []
+            for i in range(len(ranges)):
+                sent += link[i]
+                arrivals.append(sent)
+                done = max(done, sent) + t_each[i] * slowdown
+            modelled = done
+            entry['splits'].append({'widths': widths, 'product_ms': t_each, 'pipeline_ms': t_pipe, 'pack_ms': t_pack,
+                                    'copy_ms': t_copy, 'link_ms': link, 'arrival_ms': arrivals,
+                                    'slowdown_beside_exchange': slowdown, 'modelled_step_ms': modelled,
                                     'modelled_efficiency': t1 / (world * modelled)})
-            print('world %d widths %-18s products %.2f  pipeline %.2f  pack0 %.3f  copy0 %.3f  link0 %.3f  -> T_P %.2f ms, E = %.3f'
-                  % (world, widths, t_products, t_pipe, t_pack0, t_copy0, link0, modelled, t1 / (world * modelled)),
-                  flush=True)
+            print('world %d widths %-20s products %s = %.2f  pipeline %.2f  slowdown %.3f  arrivals %s -> T_P %.2f ms, E = %.3f'
+                  % (world, widths, ['%.2f' % t for t in t_each], sum(t_each), t_pipe, slowdown,
+                     ['%.2f' % t for t in arrivals], modelled, t1 / (world * modelled)), flush=True)
             plan.drop_buffers()
             torch.cuda.empty_cache()
         best = min(entry['splits'], key=lambda s_: s_['modelled_step_ms'])
