@@ -67,6 +67,17 @@ static void argument_validation() {
                                     nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_spmm_csr_out_dropout_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, x, 4, 0, 0.5f, 1, 1, nullptr, 0, 2,
                                         nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_csr_two_part_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, 1, x, 4, x, 4, 0, 1.0f, 0, 0, nullptr, 0, 4,
+                                     nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    uint32_t bits[4] = {0};
+    EXPECT(gcn_dropout_bits(4, 40, 0.5f, 1, 1, nullptr, 0, 40, bits, 1, nullptr) == GCN_ERR_BAD_ARG);   // 2 words needed
+    EXPECT(gcn_dropout_bits(4, 40, 0.0f, 1, 1, nullptr, 0, 40, bits, 2, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_dropout_bits(0, 40, 0.5f, 1, 1, nullptr, 0, 40, bits, 2, nullptr) == GCN_OK);
+    EXPECT(gcn_gemm_masked_f32(4, 4, 40, x, 40, bits, 1, 0.5f, x, 4, 0, x, 4, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_masked_f32(4, 4, 4, x, 4, nullptr, 1, 0.5f, x, 4, 0, x, 4, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_masked_f32(4, 4, 4, x, 4, bits, 1, 1.5f, x, 4, 0, x, 4, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_tn_masked_f32(4, 4, 4, x, 4, nullptr, 1, 0.5f, x, 4, x, 4, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_gemm_tn_masked_f32(4, 4, 4, x, 2, bits, 1, 0.5f, x, 4, x, 4, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_gemm_f32(4, 4, 4, nullptr, 2, nullptr, 4, 0, nullptr, 4, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_gemm_f32(4, 4, 4, nullptr, 4, nullptr, 4, 0, nullptr, 4, 64, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_gemm_f32(4, 4, 4, nullptr, 4, nullptr, 4, 0, nullptr, 4, 0, nullptr) == GCN_ERR_BAD_ARG);
@@ -120,6 +131,31 @@ static void argument_validation() {
     EXPECT(strlen(gcn_last_error_string()) > 0);
 }
 
+static void dropout_thresholds() {
+    // the integer form of the dropout predicate agrees with the float32 form on every field value
+    for (float keep : {0.5f, 0.8f, 0.9f, 0.25f, 1.0f, 0.999999f, 1e-6f, 0.3333333f}) {
+        const uint32_t t = gcn::keep_threshold(keep);
+        EXPECT(t <= 65536);
+        for (uint32_t field = 0; field < 65536; ++field) {
+            const bool by_float = gcn::passes_f32(keep, field);
+            if (by_float != (field >= t)) {
+                EXPECT(by_float == (field >= t));
+                break;
+            }
+        }
+    }
+    EXPECT(gcn::keep_threshold(1.0f) == 0 && gcn::keep_threshold(0.5f) == 32768);
+    // four consecutive ids share a hash and read its fields from the most significant one down
+    const uint64_t key = gcn::stream_key(12, 3);
+    for (uint64_t id = 0; id < 64; id += 4) {
+        const uint64_t h = gcn::decision_hash(key, id);
+        for (uint64_t e = 0; e < 4; ++e) {
+            EXPECT(gcn::decision_hash(key, id + e) == h);
+            EXPECT(gcn::decision_field(h, id + e) == ((h >> (48 - 16 * e)) & 0xffff));
+        }
+    }
+}
+
 static void long_row_tables() {
     std::mt19937_64 rng(7);
     for (int trial = 0; trial < 200; ++trial) {
@@ -161,6 +197,7 @@ static void long_row_tables() {
 int main() {
     size_queries();
     argument_validation();
+    dropout_thresholds();
     long_row_tables();
     if (g_failures) {
         fprintf(stderr, "asan_check: %d check(s) failed\n", g_failures);
