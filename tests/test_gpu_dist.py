@@ -46,7 +46,7 @@ def _worker(rank, world, port, result_dir, scale, f):
 
 
 @pytest.mark.parametrize('f', [16, 256])
-def test_two_rank_product_equals_single_gpu(f, tmp_path):
+def test_two_rank_product_equals_single_gpu(f, tmp_path, oracle):
     from gcn_amd import sparse
     scale, world = 14, 2
     port = 29700 + (os.getpid() % 1000) + f % 7
@@ -62,6 +62,15 @@ def test_two_rank_product_equals_single_gpu(f, tmp_path):
     # rows up to the split threshold are summed serially on both sides: identical bits; a longer row is
     # cut at the same places too, because a shard keeps whole rows
     assert np.array_equal(got, ref)
+    # and the two ranks against the CPU loop itself, not only through the one-GPU product
+    ip, ix, v = indptr.cpu().numpy(), indices.cpu().numpy(), vals.cpu().numpy()
+    bn = oracle.synthetic_dense(n, f, seed=7)
+    cpu = oracle.spmm_csr(ip, ix, v, bn, relu=True, threads=8)
+    short = np.diff(ip) <= (256 if f < 128 else 1024)
+    assert short.sum() > 0.95 * n
+    assert np.array_equal(got[short], cpu[short])
+    exact = np.maximum(oracle.spmm_csr_f64(ip, ix, v, bn), 0)
+    assert np.abs(got - exact).max() <= 4e-6 * max(1.0, np.abs(exact).max())
 
 
 def test_row_range_generation_equals_the_slice_of_the_whole_graph():
