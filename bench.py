@@ -47,6 +47,9 @@ def parse_args():
                     help='N>1: ranges of feature columns the exchange is pipelined over (1 = no overlap)')
     ap.add_argument('--no-autotune', action='store_true',
                     help='N>1: keep the --chunks progressive ranges instead of timing the candidate splits')
+    ap.add_argument('--in-order', action='store_true',
+                    help='N > 1: keep the single-GPU order of additions (bit-identical output) instead of multiplying '
+                         'the entries that read own rows while the exchange runs')
     ap.add_argument('--allgather', action='store_true',
                     help='N > 1: all-gather the whole of B instead of exchanging only the referenced rows')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
@@ -168,7 +171,8 @@ def planetoid_epoch_ms(name, epochs=60, hip_graph=False):
             'train_step': 'one HIP graph' if hip_graph else 'eager launches'}
 
 
-def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, classes=16, chunks=4, reorder=True):
+def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, classes=16, chunks=4, reorder=True,
+                  own_first=False):
     """One training step (forward + backward + Adam: the region train.py:203-205 times) of a 2-layer GCN
     features -> hidden -> classes on the bench graph, rows sharded over the ranks, in two forms:
 
@@ -188,7 +192,7 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, c
 
     def timed(**form):
         model = ShardedGCN(shard, x_local.shape[1], [hidden], classes, learning_rate=0.02, weight_decay=5e-4,
-                           dropout=0.5, seed=123, chunks=chunks, **form)
+                           dropout=0.5, seed=123, chunks=chunks, own_first=own_first, **form)
         for _ in range(warmup):
             model.train_step(x_local, labels, mask)
         per_step = []
@@ -490,8 +494,11 @@ def main():
         torch.distributed.all_reduce(t)
         nnz = int(t.item())
         torch.cuda.empty_cache()
-        op = gdist.HaloSpmm(shard, f, chunks=args.chunks) if not args.allgather else gdist.AllGatherSpmm(shard, f)
-        a = op.compact if not args.allgather else shard.local
+        own_first = False if args.in_order else 'auto'
+        op = (gdist.HaloSpmm(shard, f, chunks=args.chunks, own_first=own_first) if not args.allgather
+              else gdist.AllGatherSpmm(shard, f))
+        # the matrix whose kernel the roofline entry times: the one the step's last launch multiplies
+        a = op.plan.matrices[-1] if not args.allgather else shard.local
         tuned = None
         if not args.allgather and not args.no_autotune:
             # which split of the feature columns pipelines best on this communicator: measured once
@@ -545,7 +552,7 @@ def main():
                        'n_nodes': n, 'nnz': nnz, 'features': f, 'ranks_seen': seen,
                        'library_build_hash': _lib.build_hash(),
                        'library_matches_sources': _lib.build_hash() == _lib.source_hash(),
-                       'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B pipelined over column ranges %s' % (op.ranges,))) if sharded else 'single GPU'},
+                       'parallelism': ('rows/%d + %s' % (world, 'all-gather(B)' if args.allgather else 'exchange of referenced rows of B pipelined over column ranges %s%s' % (op.ranges, ', own rows multiplied first' if op.plan.own_first else ''))) if sharded else 'single GPU'},
             'pct_of_hbm_peak': 100.0 * value / (HBM_PEAK_GBPS * world),
             'gather_gbps': total_gather / (ms_per_step * 1e-3) / 1e9,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -614,7 +621,8 @@ def main():
             shares = args.chunks
             if sharded and not args.allgather:
                 shares = tuple(hi - lo for lo, hi in ranges_used)
-            epoch = rmat_epoch_ms(shard, b_local, world, chunks=shares)
+            epoch = rmat_epoch_ms(shard, b_local, world, chunks=shares,
+                                  own_first=bool(sharded and not args.allgather and not args.in_order) and 'auto')
         except Exception as exc:            # the product's line above stays valid whatever happens here
             epoch = {'error': '%s: %s' % (type(exc).__name__, exc)}
     if watchdog is not None:

@@ -74,6 +74,8 @@ SIGNATURES = {
     'gcn_spmm_csr_two_part_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64,
                                   _vp, _i64, _i64, _vp, _sz, _vp],
     'gcn_spmm_csr_add_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _sz, _vp],
+    'gcn_spmm_csr_add_out_dropout_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64,
+                                         _vp, _i64, _i64, _vp, _sz, _vp],
     'gcn_spmm_csr_dropout_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64,
                                  _vp, _vp, _sz, _vp],
     'gcn_spmm_csr_out_dropout_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64, _vp,

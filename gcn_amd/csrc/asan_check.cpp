@@ -63,6 +63,10 @@ static void argument_validation() {
     EXPECT(gcn_spmm_csr_f32_noalloc(nullptr, ip, nullptr, nullptr, 4, x, 4, x, 4, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_spmm_csr_add_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, nullptr, 4, x, 4, 0, nullptr, 0, nullptr) ==
            GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_csr_add_out_dropout_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, nullptr, 4, x, 4, 0, 0.5f, 1, 1,
+                                            nullptr, 0, 4, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    EXPECT(gcn_spmm_csr_add_out_dropout_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, x, 4, x, 4, 0, 0.5f, 1, 1, nullptr,
+                                            0, 2, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_spmm_csr_dropout_f32(nullptr, ip, nullptr, nullptr, nullptr, 4, x, 4, x, 4, 0, 0.0f, 1, 1, nullptr,
                                     nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_spmm_csr_out_dropout_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, x, 4, 0, 0.5f, 1, 1, nullptr, 0, 2,

@@ -1346,4 +1346,20 @@ int gcn_spmm_csr_out_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indpt
                              stream, nullptr, 0, &od);
 }
 
+int gcn_spmm_csr_add_out_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                                     const float* vals, int64_t f, const float* b, int64_t ldb, const float* add,
+                                     int64_t ldadd, float* c, int64_t ldc, int flags, float keep_prob, uint64_t seed,
+                                     uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset,
+                                     int64_t pitch, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!add) return fail(GCN_ERR_BAD_ARG, "addend is null");
+    if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
+    if (index_offset < 0 || pitch < f)
+        return fail(GCN_ERR_BAD_ARG, "bad decision layout: index_offset=%lld pitch=%lld for %lld columns",
+                    (long long)index_offset, (long long)pitch, (long long)f);
+    DropArgs dr = {nullptr, 0, 1.0f, 1.0f};
+    OutDrop od = {stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset, seed, stream_id};
+    return spmm_entry<false>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
+                             stream, add, ldadd, keep_prob < 1.0f ? &od : nullptr);
+}
+
 }  // extern "C"

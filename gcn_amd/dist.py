@@ -185,11 +185,24 @@ class HaloPlan(object):
     vertices have few neighbours, so a shard references a fraction of the columns (72 / 52 / 37 % at 2 / 4
     / 8 ranks on the scale-24 R-MAT), of which only the other ranks' (22 / 27 / 24 % of N) cross a link."""
 
-    def __init__(self, shard, group=None, csr_factory=None, operand_rows=None):
+    # own_first='auto': the own rows are multiplied first when they hold at least this share of the shard's entries
+    OWN_FIRST_SHARE = 0.2
+
+    def __init__(self, shard, group=None, csr_factory=None, operand_rows=None, own_first=False):
         """``operand_rows`` (ascending local row numbers, int64): the dense operand every rank passes to
         ``exchange`` holds only these rows of its block, in this order (every row of the block that anyone
-        references must be among them)."""
+        references must be among them).
+
+        ``own_first``: cut the shard by column into the entries that read the rank's own rows and the entries
+        that read received rows.  A product then multiplies the first part while the exchange is on the links
+        and adds the second, range by range, as the rows arrive (``halo_product``): the work that needs no
+        exchange hides the exchange.  A row's own-block entries are then summed before its other entries, not
+        in column order: deterministic, equal to the single-GPU product to rounding (1e-5 of the largest
+        element), no longer bit for bit.  False keeps the single-GPU order and bits.  'auto': True when the own
+        part holds at least ``OWN_FIRST_SHARE`` of the shard's entries (2 and 4 ranks of an evenly spread
+        graph), decided per rank from its own counts."""
         self.shard, self.group = shard, group
+        self.own_first, self.own, self.remote = False, None, None
         local = shard.local
         dev = local.device
         world = shard.world
@@ -244,8 +257,26 @@ class HaloPlan(object):
                 raise ValueError('a requested row is not among operand_rows')
         self.n_remote = int(remote.numel())
         make = csr_factory or sparse.DeviceCSR
-        self.compact = make(local.n_rows, self.n_first + self.n_remote, local.indptr, new_cols, local.values)
         self._identity = False
+        in_own = new_cols < self.n_first
+        before = torch.zeros(local.nnz + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(in_own, dim=0, out=before[1:])
+        if own_first == 'auto':
+            own_first = world > 1 and local.nnz > 0 and int(before[-1]) >= self.OWN_FIRST_SHARE * local.nnz
+        self.own_first = bool(own_first)
+        if not self.own_first:
+            del in_own, before
+            self.compact = make(local.n_rows, self.n_first + self.n_remote, local.indptr, new_cols, local.values)
+            return
+        # two matrices over the same rows; the order of the entries inside a row is kept in both
+        own_indptr = before[local.indptr].contiguous()
+        del before
+        self.own = make(local.n_rows, self.n_first, own_indptr, new_cols[in_own].contiguous(),
+                        local.values[in_own].contiguous())
+        in_own.logical_not_()
+        self.remote = make(local.n_rows, self.n_remote, local.indptr - own_indptr,
+                           (new_cols[in_own] - self.n_first).contiguous(), local.values[in_own].contiguous())
+        self.compact = None
 
     def multiply(self, b_local, received, relu=False, out=None, spmm=None, **extra):
         """``compact . [b_local; received]`` without stacking the two parts (``sparse.spmm(first=...)``); a
@@ -254,9 +285,31 @@ class HaloPlan(object):
             return (spmm or sparse.spmm)(self.compact, b_local, relu=relu, out=out, **extra)
         if b_local.shape[0] != self.n_first:
             raise ValueError('the operand has %d rows, the plan expects %d' % (b_local.shape[0], self.n_first))
+        if self.own_first:
+            out = self.multiply_own(b_local, out=out, spmm=spmm, wide_split=extra.get('wide_split', False))
+            return self.add_remote(received, out, relu=relu, spmm=spmm, **extra)
         if spmm is None or spmm is sparse.spmm:
             return sparse.spmm(self.compact, received, relu=relu, out=out, first=b_local, **extra)
         return spmm(self.compact, torch.cat([b_local, received]), relu=relu, out=out, **extra)
+
+    def multiply_own(self, b_local, out=None, spmm=None, wide_split=False):
+        """First half of an own-first product: ``own . b_local`` (no activation: the sum is not complete)."""
+        if spmm is None or spmm is sparse.spmm:
+            return sparse.spmm(self.own, b_local, out=out, wide_split=wide_split)
+        return spmm(self.own, b_local, out=out)
+
+    def add_remote(self, received, partial, relu=False, spmm=None, **extra):
+        """Second half: ``partial <- act(remote . received + partial)`` in place, with the store dropout of
+        ``extra['out_dropout']`` if given.  ``partial`` may be a column range of the first half's output."""
+        if spmm is None or spmm is sparse.spmm:
+            return sparse.spmm_add(self.remote, received, partial, relu=relu, out=partial, **extra)
+        # a multiply function of the caller's (the CPU oracle in tests) takes the addend as ``add=``
+        return spmm(self.remote, received, relu=relu, out=partial, add=partial, **extra)
+
+    @property
+    def matrices(self):
+        """The CSR matrices a product of this plan multiplies (one, or the own and the remote part)."""
+        return (self.own, self.remote) if self.own_first else (self.compact,)
 
     def drop_buffers(self, keep_widths=()):
         """Free the cached send / receive buffers of every width not in ``keep_widths``."""
@@ -378,16 +431,19 @@ def column_chunks(f, chunks, progressive=True):
 class HaloSpmm(object):
     """C_local = A_local . B where every rank receives only the rows of B its shard references.
 
+    ``own_first`` (see HaloPlan): the entries that read the rank's own rows are multiplied while the exchange
+    is on the links; off by default, which keeps the bits of the single-GPU product.
+
     With ``chunks`` > 1 the feature columns are cut into that many ranges whose exchanges are all issued
     at once and follow each other on the links while the products of the ranges that have arrived run
     (each output column depends on the same column of B only, and every row still accumulates in
     storage order, so the result does not change by a bit).  The first range's exchange is the only one
     the product waits for."""
 
-    def __init__(self, shard, f, group=None, spmm=None, csr_factory=None, plan=None, chunks=1):
+    def __init__(self, shard, f, group=None, spmm=None, csr_factory=None, plan=None, chunks=1, own_first=False):
         self.shard, self.f = shard, f
         self._spmm = spmm or sparse.spmm
-        self.plan = plan or HaloPlan(shard, group=group, csr_factory=csr_factory)
+        self.plan = plan or HaloPlan(shard, group=group, csr_factory=csr_factory, own_first=own_first)
         self.compact = self.plan.compact
         self.n_remote = self.plan.n_remote
         self.recv_splits = self.plan.recv_splits
@@ -458,6 +514,17 @@ def halo_product(plan, b_local, out, relu=False, ranges=None, spmm=None, out_dro
     if out_dropout is not None:
         out_dropout = sparse.OutDropout(out_dropout.keep_prob, out_dropout.seed, out_dropout.stream_id,
                                         out_dropout.index_offset, f)
+    if plan.own_first:
+        # the exchange of every range goes out, the entries that read own rows are multiplied meanwhile, then
+        # each range's received rows are multiplied and added to what is there
+        handles = plan.exchange_ranges(b_local, ranges)
+        plan.multiply_own(b_local, out=out, spmm=spmm, wide_split=False)
+        for (c0, c1), (rows, work) in zip(ranges, handles):
+            work.wait()
+            if out_dropout is not None:
+                extra['out_dropout'] = out_dropout.columns(c0)
+            plan.add_remote(rows, out[:, c0:c1], relu=relu, spmm=spmm, wide_split=f >= 128, **extra)
+        return out
     if len(ranges) == 1:
         if out_dropout is not None:
             extra['out_dropout'] = out_dropout

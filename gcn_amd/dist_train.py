@@ -19,7 +19,7 @@ from .models import TfAdam
 
 def _product(plan, b_local, relu, chunks, out_dropout=None):
     """A_local . exchange(B) into a fresh tensor; wide operands pipeline the exchange over column ranges."""
-    out = torch.empty((plan.compact.n_rows, b_local.shape[1]), dtype=torch.float32, device=b_local.device)
+    out = torch.empty((plan.shard.local.n_rows, b_local.shape[1]), dtype=torch.float32, device=b_local.device)
     f = b_local.shape[1]
     if f < 128:
         ranges = [(0, f)]
@@ -105,8 +105,11 @@ class ShardedGCN(object):
 
     def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
                  seed=0, group=None, chunks=4, aggregate_first=None, receptive_field=True, labelled_logits_only=True,
-                 reorder=None):
-        """``reorder`` ('degree', 'hubs' or ('hubs', K); one rank only): the model works on the graph with its
+                 reorder=None, own_first=False):
+        """``own_first`` (False, True or 'auto'): handed to every HaloPlan of the model (see dist.HaloPlan): the
+        entries that read a rank's own rows are multiplied while the exchange is on the links.
+
+        ``reorder`` ('degree', 'hubs' or ('hubs', K); one rank only): the model works on the graph with its
         vertices relabelled once (utils.vertex_order); features, labels and masks given in the dataset's order
         are permuted on their way in (once per tensor object) and ``forward`` returns its rows in the dataset's
         order.  Dropout decisions are then drawn by the new row numbers."""
@@ -123,7 +126,8 @@ class ShardedGCN(object):
         self.shard, self.group = shard, group
         # ranges of feature columns an exchange is pipelined over: a count, or a tuple of width shares
         self.chunks = chunks if shard.world > 1 else 1
-        self.plan = HaloPlan(shard, group=group)
+        self.own_first = own_first
+        self.plan = HaloPlan(shard, group=group, own_first=own_first)
         self.dropout, self.wd, self.seed = float(dropout), float(weight_decay), int(seed)
         sizes = [f_in] + list(layer_size) + [n_classes]
         self.aggregate_first = (f_in <= sizes[1]) if aggregate_first is None else bool(aggregate_first)
@@ -168,8 +172,9 @@ class ShardedGCN(object):
                 all_gather_rows(everyone, flags.contiguous(), group=self.group)
             else:
                 everyone = flags
-            backward = HaloPlan(shard_with_columns(self.shard, everyone != 0), group=self.group)
-            forward = HaloPlan(shard_with_rows(self.shard, flags != 0), group=self.group)
+            backward = HaloPlan(shard_with_columns(self.shard, everyone != 0), group=self.group,
+                                own_first=self.own_first)
+            forward = HaloPlan(shard_with_rows(self.shard, flags != 0), group=self.group, own_first=self.own_first)
             hit = (mask_local, (forward, backward))
             self._grad_plans[id(mask_local)] = hit
         return hit[1]
@@ -205,10 +210,11 @@ class ShardedGCN(object):
                 'rows': r_local,
                 'row_ids': (r_local + self.shard.row_begin).contiguous(),
                 'labelled': lab_rows,
-                'wide': HaloPlan(shard_rows_compacted(self.shard, r_local), group=self.group),
-                'logits': HaloPlan(shard_rows_compacted(self.shard, lab_rows), group=self.group, operand_rows=r_local),
+                'wide': HaloPlan(shard_rows_compacted(self.shard, r_local), group=self.group, own_first=self.own_first),
+                'logits': HaloPlan(shard_rows_compacted(self.shard, lab_rows), group=self.group, operand_rows=r_local,
+                                   own_first=self.own_first),
                 'back': HaloPlan(shard_rows_compacted(shard_with_columns(self.shard, everyone), r_local),
-                                 group=self.group, operand_rows=lab_rows),
+                                 group=self.group, operand_rows=lab_rows, own_first=self.own_first),
             }
             hit = (mask_local, plans)
             self._grad_plans[('receptive', id(mask_local))] = hit

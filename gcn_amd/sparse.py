@@ -517,8 +517,10 @@ def spmm_noalloc(a, b, out, relu=False):
     return out
 
 
-def spmm_add(a, b, d, relu=False, out=None):
-    """``a @ b + d`` with the addition fused into the product's epilogue (one smoothing step)."""
+def spmm_add(a, b, d, relu=False, out=None, wide_split=False, out_dropout=None):
+    """``a @ b + d`` with the addition fused into the product's epilogue (one smoothing step): every row is
+    summed as ``spmm`` sums it and ``d``'s row is added last.  ``out`` may be ``d`` itself (each element is read
+    and then written by the same lane).  ``wide_split`` and ``out_dropout`` as in ``spmm``."""
     _require_cuda(b, d)
     b, d = _rowmajor(b), _rowmajor(d)
     if b.shape[0] != a.n_cols or d.shape != (a.n_rows, b.shape[1]):
@@ -526,9 +528,20 @@ def spmm_add(a, b, d, relu=False, out=None):
     f = b.shape[1]
     if out is None:
         out = torch.empty((a.n_rows, f), dtype=torch.float32, device=b.device)
+    else:
+        _check_out(out, a.n_rows, f)
     ws, ws_bytes = a.plan.workspace(f, b.device)
+    flags = (_lib.GCN_RELU if relu else 0) | (_lib.GCN_SPLIT_WIDE if wide_split else 0)
+    if out_dropout is not None and out_dropout.keep_prob < 1.0:
+        o = out_dropout
+        if o.row_ids is not None:
+            raise ValueError('row_ids apply to dense products only')
+        _lib.call('gcn_spmm_csr_add_out_dropout_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f,
+                  _p(b), _ld(b), _p(d), _ld(d), _p(out), _ld(out), flags, o.keep_prob, o.seed, o.stream_id,
+                  _p(_stream_offset), o.index_offset, f if o.pitch is None else int(o.pitch), _p(ws), ws_bytes, _stream())
+        return out
     _lib.call('gcn_spmm_csr_add_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(b), _ld(b),
-              _p(d), _ld(d), _p(out), _ld(out), _lib.GCN_RELU if relu else 0, _p(ws), ws_bytes, _stream())
+              _p(d), _ld(d), _p(out), _ld(out), flags, _p(ws), ws_bytes, _stream())
     return out
 
 

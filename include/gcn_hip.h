@@ -267,7 +267,8 @@ int gcn_spmm_csr_two_part_f32(const gcn_spmm_plan* plan, const int64_t* indptr, 
 
 /* C = A . B + D: one smoothing / propagation step with the residual added in the epilogue
  * (`new_feature = adj * new_feature + features`, gcn/utils.py:568-569; float32 here).  D is a
- * dense [n_rows x f] matrix; GCN_RELU applies after the addition. */
+ * dense [n_rows x f] matrix; GCN_RELU applies after the addition.  C may be D itself (every element is
+ * read and then written by the same lane). */
 int gcn_spmm_csr_add_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
                          int64_t f, const float* b, int64_t ldb, const float* add, int64_t ldadd, float* c,
                          int64_t ldc, int flags, void* workspace, size_t workspace_bytes, void* stream);
@@ -298,6 +299,18 @@ int gcn_spmm_csr_out_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indpt
                                  int flags, float keep_prob, uint64_t seed, uint64_t stream_id,
                                  const uint64_t* stream_offset, int64_t index_offset, int64_t pitch, void* workspace,
                                  size_t workspace_bytes, void* stream);
+
+/* C = dropout(act(A . B + D)): gcn_spmm_csr_add_f32 with the store dropout of gcn_spmm_csr_out_dropout_f32
+ * (same decision ids).  A row-partitioned layer product (gcn/layers.py:202-208) that multiplies the entries
+ * reading the rank's own rows while the other ranks' rows are still on the links finishes with this call:
+ * D is that first partial product, A the entries that read received rows, and the activation and the next
+ * layer's dropout (gcn/layers.py:185) are applied once, in this store.  C may be D itself: every element is read
+ * and then written by the same lane.  The single-process reference has no counterpart. */
+int gcn_spmm_csr_add_out_dropout_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices,
+                                     const float* vals, int64_t f, const float* b, int64_t ldb, const float* add,
+                                     int64_t ldadd, float* c, int64_t ldc, int flags, float keep_prob, uint64_t seed,
+                                     uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset,
+                                     int64_t pitch, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Dense pieces of the layer.                                                 *

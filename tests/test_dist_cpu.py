@@ -27,9 +27,13 @@ class _HostCSR(object):
         return int(self.indices.numel())
 
 
-def _oracle_spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None):
+def _oracle_spmm(a, b, relu=False, out=None, wide_split=False, out_dropout=None, add=None):
     import gcn_oracle
-    c = gcn_oracle.spmm_csr(a.indptr.numpy(), a.indices.numpy(), a.values.numpy(), b.numpy(), relu=relu)
+    c = gcn_oracle.spmm_csr(a.indptr.numpy(), a.indices.numpy(), a.values.numpy(), b.numpy(), relu=relu and add is None)
+    if add is not None:                         # the addend after the row's own sum, then the activation
+        c = c + add.numpy()
+        if relu:
+            c = np.maximum(c, 0)
     if out_dropout is not None:                 # decision ids as the HIP store computes them
         d = out_dropout
         pitch = c.shape[1] if d.pitch is None else d.pitch
@@ -88,6 +92,38 @@ def _worker(rank, world, port, result_dir):
             got = gdist.halo_product(halo.plan, torch.from_numpy(b[r0:r1].copy()), torch.empty_like(c_local), True,
                                      ranges, _oracle_spmm, out_dropout=drop)
             assert np.array_equal(got.numpy(), want)
+        # own rows first: the entries that read the rank's own block are summed before the others (the part
+        # that can run while the exchange is on the links).  Bit for bit what the CPU loop gives for that order
+        # of additions -- own entries, then the other entries, then the two sums added --, whole or range by
+        # range, with the activation and the store dropout applied once at the end; and equal to the in-order
+        # product to rounding.
+        ip, ix, v = local.indptr.numpy(), local.indices.numpy(), local.values.numpy()
+        own = (ix >= r0) & (ix < r1)
+        row_of = np.repeat(np.arange(r1 - r0), np.diff(ip))
+
+        def part(keep):
+            cnt = np.bincount(row_of[keep], minlength=r1 - r0)
+            return np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), ix[keep], v[keep]
+        first = gcn_oracle.spmm_csr(*part(own), b)
+        both = np.maximum(gcn_oracle.spmm_csr(*part(~own), b) + first, 0)
+        assert np.abs(both - c_local.numpy()).max() <= 1e-6 * np.abs(c_local.numpy()).max()
+        own_plan = gdist.HaloPlan(shard, csr_factory=_HostCSR, own_first=True)
+        assert own_plan.own_first and own_plan.compact is None
+        assert own_plan.own.nnz == int(own.sum()) and own_plan.remote.nnz == int((~own).sum())
+        assert own_plan.own.n_cols == r1 - r0 and own_plan.remote.n_cols == own_plan.n_remote == halo.n_remote
+        want_dropped, _ = gcn_oracle.dense_dropout(both, 0.5, gcn_oracle.stream_key(11, 3), index_offset=r0 * f)
+        for ranges in ([(0, f)], [(0, 4), (4, 8), (8, 16)]):
+            got = gdist.halo_product(own_plan, torch.from_numpy(b[r0:r1].copy()), torch.empty_like(c_local), True,
+                                     ranges, _oracle_spmm)
+            assert np.array_equal(got.numpy(), both)
+            got = gdist.halo_product(own_plan, torch.from_numpy(b[r0:r1].copy()), torch.empty_like(c_local), True,
+                                     ranges, _oracle_spmm, out_dropout=drop)
+            assert np.array_equal(got.numpy(), want_dropped)
+        assert np.array_equal(own_plan.multiply(torch.from_numpy(b[r0:r1].copy()),
+                                                own_plan.exchange(torch.from_numpy(b[r0:r1].copy())), relu=True,
+                                                out=torch.empty_like(c_local), spmm=_oracle_spmm).numpy(), both)
+        auto = gdist.HaloPlan(shard, csr_factory=_HostCSR, own_first='auto')
+        assert auto.own_first == (own.sum() >= 0.2 * own.size)
         # the pipeline is picked by measurement; a rigged clock makes the choice predictable, the
         # MAX over ranks makes it the same everywhere, and the result does not change
         ticks = iter(range(1000))

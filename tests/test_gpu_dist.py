@@ -41,6 +41,14 @@ def _worker(rank, world, port, result_dir, scale, f):
         piped = gdist.HaloSpmm(shard, f, plan=halo.plan, chunks=4)
         assert torch.equal(piped(b_local, relu=True), c_halo)
         np.save(os.path.join(result_dir, 'c_%d.npy' % rank), c_halo.cpu().numpy())
+        # own rows first (the part of the product that hides the exchange): one range and three, twice each
+        own = gdist.HaloSpmm(shard, f, own_first=True)
+        assert own.plan.own_first and own.plan.own.nnz + own.plan.remote.nnz == shard.local.nnz
+        c_own = own(b_local, relu=True).clone()
+        assert torch.equal(own(b_local, relu=True), c_own)
+        own3 = gdist.HaloSpmm(shard, f, plan=own.plan, chunks=3)
+        assert len(own3.ranges) == 3 and torch.equal(own3(b_local, relu=True), c_own)
+        np.save(os.path.join(result_dir, 'own_%d.npy' % rank), c_own.cpu().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -71,6 +79,20 @@ def test_two_rank_product_equals_single_gpu(f, tmp_path, oracle):
     assert np.array_equal(got[short], cpu[short])
     exact = np.maximum(oracle.spmm_csr_f64(ip, ix, v, bn), 0)
     assert np.abs(got - exact).max() <= 4e-6 * max(1.0, np.abs(exact).max())
+    # own rows first: another order of the same additions -- the same product to rounding, and on the rows
+    # short enough to be summed serially exactly what the CPU loop gives for that order
+    own = np.concatenate([np.load(os.path.join(str(tmp_path), 'own_%d.npy' % r)) for r in range(world)])
+    assert np.abs(own - exact).max() <= 4e-6 * max(1.0, np.abs(exact).max())
+    assert not np.array_equal(own, got)
+    per = n // world
+    block = np.repeat(np.arange(n), np.diff(ip)) // per
+    mine = (ix // per) == block
+
+    def part(keep):
+        cnt = np.bincount(np.repeat(np.arange(n), np.diff(ip))[keep], minlength=n)
+        return np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), ix[keep], v[keep]
+    cpu_own = np.maximum(oracle.spmm_csr(*part(~mine), bn, threads=8) + oracle.spmm_csr(*part(mine), bn, threads=8), 0)
+    assert np.array_equal(own[short], cpu_own[short])
 
 
 def test_row_range_generation_equals_the_slice_of_the_whole_graph():
@@ -223,7 +245,7 @@ def test_rccl_entry_points_of_the_c_abi(tmp_path):
     assert (tmp_path / 'ok').exists()
 
 
-def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first):
+def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first, own_first=False):
     if world > 1:
         faulthandler.dump_traceback_later(90, exit=True)
     sys.path.insert(0, ROOT)
@@ -247,7 +269,8 @@ def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first):
         labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32)[r0:r1].cuda()
         mask = (torch.rand(n, generator=gen) < 0.05).to(torch.int32)[r0:r1].cuda()
         model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9,
-                           aggregate_first=aggregate_first)
+                           aggregate_first=aggregate_first, own_first=own_first)
+        assert model.plan.own_first == (bool(own_first) and world > 1)
         losses = [float(model.train_step(x, labels, mask)) for _ in range(steps)]
         if rank == 0:
             np.save(os.path.join(result_dir, 'loss_w%d.npy' % world), np.array(losses))
@@ -269,6 +292,22 @@ def test_sharded_training_step_matches_single_gpu(tmp_path, aggregate_first):
                        join=True, start_method='spawn')
     l1, l2 = np.load(tmp_path / 'loss_w1.npy'), np.load(tmp_path / 'loss_w2.npy')
     assert np.all(np.isfinite(l1)) and l1[-1] < l1[0]
+    assert np.allclose(l1, l2, rtol=1e-5)
+    w1, w2 = np.load(tmp_path / 'w0_w1.npy'), np.load(tmp_path / 'w0_w2.npy')
+    d = np.abs(w1 - w2)
+    assert (d <= 1e-5 * np.abs(w1).max()).mean() >= 0.999 and d.max() <= 1e-3 * np.abs(w1).max()
+
+
+@pytest.mark.parametrize('aggregate_first', [False, True])
+def test_sharded_training_step_with_own_rows_first(tmp_path, aggregate_first):
+    """The same comparison with every plan of the 2-rank model cut into the entries that read own rows (multiplied
+    while the exchange runs) and the rest (added as the rows arrive, activation and dropout in that last store)."""
+    scale, steps = 13, 4
+    port = 29900 + (os.getpid() % 1000) + (7 if aggregate_first else 0)
+    _train_worker(0, 1, port, str(tmp_path), scale, steps, aggregate_first)
+    mp.start_processes(_train_worker, args=(2, port + 1, str(tmp_path), scale, steps, aggregate_first, True), nprocs=2,
+                       join=True, start_method='spawn')
+    l1, l2 = np.load(tmp_path / 'loss_w1.npy'), np.load(tmp_path / 'loss_w2.npy')
     assert np.allclose(l1, l2, rtol=1e-5)
     w1, w2 = np.load(tmp_path / 'w0_w1.npy'), np.load(tmp_path / 'w0_w2.npy')
     d = np.abs(w1 - w2)

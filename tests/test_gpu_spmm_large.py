@@ -87,6 +87,20 @@ def test_addend_and_store_dropout_forms_on_the_large_matrix(big_hat, oracle, f):
         c0, c1 = 32, 96
         part = sparse.spmm(a, b[:, c0:c1], wide_split=True)
         assert torch.equal(part, plain[:, c0:c1])
+    # the addend may be the output itself, whole or a column range; activation and store dropout after the sum
+    summed = plain + dmat
+    inplace = dmat.clone()
+    assert sparse.spmm_add(a, b, inplace, out=inplace) is inplace and torch.equal(inplace, summed)
+    if f >= 128:
+        inplace = dmat.clone()
+        for c0, c1 in ((0, 32), (32, 96), (96, f)):
+            sparse.spmm_add(a, b[:, c0:c1], inplace[:, c0:c1], out=inplace[:, c0:c1], wide_split=True)
+        assert torch.equal(inplace, summed)
+    inplace = dmat.clone()
+    sparse.spmm_add(a, b, inplace, relu=True, out=inplace, out_dropout=sparse.OutDropout(keep_prob, 31, 2, index_offset=8 * f))
+    ref, _ = oracle.dense_dropout(np.maximum(summed.cpu().numpy(), 0), keep_prob, oracle.stream_key(31, 2),
+                                  index_offset=8 * f)
+    assert np.array_equal(inplace.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize('f', [16, 64, 128, 256, 512])

@@ -59,9 +59,68 @@ def stand_in_plan(shard, per):
     plan.n_first, plan.n_remote = per, int(remote.numel())
     plan.compact = sparse.DeviceCSR(local.n_rows, per + plan.n_remote, local.indptr, new_cols, local.values)
     plan._identity, plan._collective, plan._buffers, plan._side = False, False, {}, None
+    plan.own_first, plan.own, plan.remote = False, None, None
     plan.send_rows = torch.randint(0, per, (plan.n_remote,), device=local.device)
     referenced_own = int(torch.unique(cols[mine]).numel())
     return plan, referenced_own
+
+
+def own_and_remote(plan):
+    """The compact matrix cut by column: the entries that read the rank's own rows, and the entries that read
+    received rows (columns renumbered from 0), entry order inside a row unchanged."""
+    a = plan.compact
+    own = a.indices < plan.n_first
+    rows = torch.repeat_interleave(torch.arange(a.n_rows, device=a.device), a.indptr[1:] - a.indptr[:-1])
+
+    def part(keep, shift, n_cols):
+        counts = torch.bincount(rows[keep], minlength=a.n_rows)
+        indptr = torch.zeros(a.n_rows + 1, dtype=torch.int64, device=a.device)
+        torch.cumsum(counts, 0, out=indptr[1:])
+        return sparse.DeviceCSR(a.n_rows, n_cols, indptr, (a.indices[keep] - shift).contiguous(), a.values[keep].contiguous())
+
+    return part(own, 0, plan.n_first), part(~own, plan.n_first, plan.n_remote)
+
+
+def own_first(plan, a_own, a_remote, b_local, out, ranges):
+    """The product with the part that needs no exchange first: every range's exchange is issued, the own-rows
+    product of the full width runs while they are on the links, then each range's received rows are multiplied
+    and added to what is there."""
+    plan.own_first, plan.own, plan.remote = True, a_own, a_remote
+    try:
+        return gdist.halo_product(plan, b_local, out, False, ranges)
+    finally:
+        plan.own_first = False
+
+
+def own_first_report(world, plan, b_local, out, halo, t1, links, recv_rows, f):
+    a_own, a_remote = own_and_remote(plan)
+    t_own = timed(lambda: sparse.spmm(a_own, b_local, out=out))
+    print('world %d own-first: own part %d entries %.2f ms, remote part %d entries' % (world, a_own.nnz, t_own, a_remote.nnz),
+          flush=True)
+    rows = []
+    for shares in gdist.HaloSpmm.CANDIDATES + ((1, 1, 1, 1), (1, 1, 1, 1, 1, 1, 1, 1)):
+        ranges = gdist.column_shares(f, shares)
+        widths = [hi - lo for lo, hi in ranges]
+        t_each = [timed(lambda lo=lo, hi=hi: sparse.spmm_add(a_remote, halo[:, lo:hi], out[:, lo:hi], out=out[:, lo:hi],
+                                                             wide_split=f >= 128)) for lo, hi in ranges]
+        t_pipe = timed(lambda: own_first(plan, a_own, a_remote, b_local, out, ranges))
+        bufs = [plan._buffers_for(w, i, b_local.device) for i, w in enumerate(widths)]
+        t_pack0 = timed(lambda: sparse.gather_rows(b_local[:, ranges[0][0]:ranges[0][1]], plan.send_rows, bufs[0][0]))
+        link = [recv_rows * w * 4 / (links * LINK_GBPS * 1e9) * 1e3 for w in widths]
+        slowdown = max(1.0, t_pipe / (t_own + sum(t_each)))
+        sent, done, arrivals = t_pack0, t_own * slowdown, []
+        for i in range(len(ranges)):
+            sent += link[i]
+            arrivals.append(sent)
+            done = max(done, sent) + t_each[i] * slowdown
+        rows.append({'widths': widths, 'own_ms': t_own, 'remote_ms': t_each, 'pipeline_ms': t_pipe, 'slowdown': slowdown,
+                     'arrival_ms': arrivals, 'modelled_step_ms': done, 'modelled_efficiency': t1 / (world * done)})
+        print('world %d own-first widths %-28s own %.2f + remote %s = %.2f  pipeline %.2f  slowdown %.3f  arrivals %s -> T_P %.2f ms, E = %.3f'
+              % (world, widths, t_own, ['%.2f' % t for t in t_each], t_own + sum(t_each), t_pipe, slowdown,
+                 ['%.2f' % t for t in arrivals], done, t1 / (world * done)), flush=True)
+        plan.drop_buffers()
+        torch.cuda.empty_cache()
+    return rows
 
 
 def main():
@@ -69,6 +128,7 @@ def main():
     ap.add_argument('--scale', type=int, default=24)
     ap.add_argument('--features', type=int, default=256)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--own-first', action='store_true', help='only the form that multiplies the own rows first')
     args = ap.parse_args()
     scale, f = args.scale, args.features
     n = 1 << scale
@@ -97,7 +157,9 @@ def main():
                  'referenced_share_of_n': (own + plan.n_remote) / n, 'rows_over_links': recv_rows,
                  'received_gb_per_product': recv_rows * f * 4 / 1e9, 'local_product_full_width_ms': t_full,
                  'link_total_ms': recv_rows * f * 4 / (links * LINK_GBPS * 1e9) * 1e3, 'splits': []}
-        for shares in gdist.HaloSpmm.CANDIDATES:
+        if args.own_first:
+            entry['own_first'] = own_first_report(world, plan, b_local, out, halo, t1, links, recv_rows, f)
+        for shares in (() if args.own_first else gdist.HaloSpmm.CANDIDATES):
             ranges = gdist.column_shares(f, shares)
             widths = [hi - lo for lo, hi in ranges]
 
@@ -140,6 +202,13 @@ def main():
                      ['%.2f' % t for t in arrivals], modelled, t1 / (world * modelled)), flush=True)
             plan.drop_buffers()
             torch.cuda.empty_cache()
+        if args.own_first:
+            best = min(entry['own_first'], key=lambda s_: s_['modelled_step_ms'])
+            print('world %d own-first best %s: E = %.3f' % (world, best['widths'], best['modelled_efficiency']), flush=True)
+            report['worlds'].append(entry)
+            del shard, plan, halo, out, b_local
+            torch.cuda.empty_cache()
+            continue
         best = min(entry['splits'], key=lambda s_: s_['modelled_step_ms'])
         entry['best'] = best
         report['worlds'].append(entry)
