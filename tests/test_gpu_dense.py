@@ -50,7 +50,10 @@ def test_gemm_mfma_against_float64(oracle, m, n, k, trans_b):
     assert np.array_equal(out_relu, np.maximum(out, 0))
 
 
-@pytest.mark.parametrize('m,n,k', [(128, 128, 32), (5000, 256, 64), (1000, 384, 96), (257, 128, 512), (1280, 512, 256)])
+@pytest.mark.parametrize('m,n,k', [(128, 128, 32), (5000, 256, 64), (1000, 384, 96), (257, 128, 512), (1280, 512, 256),
+                                   # 16 column tiles or more: the block order that walks groups of 8 panels (whole
+                                   # groups, a last group of 3 rows of panels, fewer panels than one group)
+                                   (128 * 19 + 7, 2048, 64), (128 * 64, 2304, 32), (300, 2048, 32)])
 @pytest.mark.parametrize('trans_b', [False, True])
 def test_whole_panel_form_gives_the_bits_of_the_guarded_form(oracle, m, n, k, trans_b):
     """Whole 128-row panels with n a multiple of 128 and k of 32 go through the kernel without guards
