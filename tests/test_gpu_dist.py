@@ -185,6 +185,12 @@ def _single_rank_rccl_worker(rank, port, result_dir):
         assert torch.equal(piped(b, relu=True), ref)
         gathered = gdist.AllGatherSpmm(shard, f)(b, relu=True)
         assert torch.equal(gathered, ref)
+        # own rows first over RCCL: with one rank every entry reads an own row, the part added afterwards is
+        # empty (activation in its store all the same) and the bits are the in-order ones
+        own = gdist.HaloSpmm(shard, f, chunks=4, own_first=True)
+        assert own.plan.own_first and own.plan.remote.nnz == 0 and own.plan.own.nnz == shard.local.nnz
+        for _ in range(2):
+            assert torch.equal(own(b, relu=True), ref)
         t = torch.ones(4, device='cuda')
         gdist.all_reduce_sum(t)
         assert float(t.sum()) == 4.0
