@@ -957,6 +957,134 @@ static int launch_gemm(int64_t m, int64_t n, int64_t k, const float* a, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// C[m x n] = act(A[m x k] . B[k x n]) for n <= 32 (hidden -> classes, gcn/layers.py:32-33 on the last layer):
+// A is read once, C is n / k of it, so the product is bound by HBM -- as long as nothing else is in the way.
+// The tiled kernel above pads n = 16 to a 32-column MFMA tile and its loads, LDS stores, barriers and MFMAs take
+// turns.  Here
+//  - the MFMA is v_mfma_f32_16x16x4_f32: a 16-column tile, no padding at n = 16;
+//  - A goes from global memory straight into the MFMA operand registers: lane (i = lane % 16, g = lane / 16)
+//    loads the four consecutive k  k0 + 4 g .. k0 + 4 g + 3  of its row as one 128-bit load per 16-k step and
+//    feeds element e to the e-th MFMA of the step, whose four lane groups thus cover k0 + e, k0 + 4 + e,
+//    k0 + 8 + e, k0 + 12 + e; B (at most 64 KB) sits in LDS in that order.  No LDS traffic for A, no barrier in
+//    the loop, the next step's loads in flight during the MFMAs of this one;
+//  - a wave owns 16 rows at a time and requests 1 KiB of each of them (sixteen 16-k steps) before it uses the
+//    first; the tiles are walked with a grid stride.
+// 2^24 x 256 x 16: 3.65 ms against 3.72-3.85 ms of the tiled kernel (5.0 TB/s; see the note at the stores).
+// Order of additions of an output element: steps in ascending k, inside a step e = 0..3, inside an MFMA the
+// hardware's fixed order over its four k.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(kBlock) void gemm_skinny_kernel(int64_t m, int n, int k, const float* __restrict__ a,
+                                                            int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                            float* __restrict__ c, int64_t ldc, int relu,
+                                                            int64_t n_tiles, int c_vec) {
+    constexpr int kCols = 16 * NT;
+    constexpr int kTrPitch = 20;           // of a wave's 16 x 16 output tile in LDS: conflict-free both ways
+    constexpr int kPitch = kCols + 4;      // rows 4 apart (the four lane groups of a fragment read) 16 banks apart
+    constexpr int kSteps = 16;             // 16-k steps requested together: 1 KiB of every row
+    extern __shared__ __attribute__((aligned(16))) float skinny_b[];
+    for (int idx = threadIdx.x; idx < k * kCols; idx += kBlock) {
+        const int kk = idx / kCols, col = idx % kCols;
+        skinny_b[kk * kPitch + col] = col < n ? b[(int64_t)kk * ldb + col] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+    const int steps = k / 16;
+    for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const int64_t row0 = tile * 16;
+        const int64_t row = min(row0 + i, m - 1);                    // rows past the end repeat the last one
+        const float* src = a + row * lda + 4 * g;
+        f32x4v acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int s0 = 0; s0 < steps; s0 += kSteps) {
+            // every line of the rows' next 1 KiB is requested before the first is used: the 16 rows of a tile
+            // are 16 runs of consecutive lines for the memory system, not 16 x 8 separate visits
+            f32x4v av[kSteps];
+#pragma unroll
+            for (int u = 0; u < kSteps; ++u)
+                if (s0 + u < steps) av[u] = *reinterpret_cast<const f32x4v*>(src + (s0 + u) * 16);
+#pragma unroll
+            for (int u = 0; u < kSteps; ++u) {
+                if (s0 + u < steps) {
+                    const float* frag = skinny_b + ((s0 + u) * 16 + 4 * g) * kPitch + i;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], frag[e * kPitch + 16 * t], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // Lane (j = lane % 16, g) holds rows 4 g .. 4 g + 3 of column j of every 16 x 16 tile: stored as it stands,
+        // a wave instruction writes four 64-byte pieces.  The tile goes through 1.25 KiB of LDS private to the
+        // wave instead, and lane l writes the four consecutive columns 4 (l % 4) .. of row l / 4: one 128-bit store
+        // per lane, 1 KiB contiguous per instruction when C's rows are 16 floats.  (What the output costs is not
+        // its shape: on 2^24 x 256 x 16 the kernel takes 2.85 ms with the stores removed or confined to the L2 --
+        // 6.1 TB/s, the rate of a pure read sweep -- and 3.65 ms with the 1 GB of C going to HBM, in 64-byte
+        // pieces, in whole lines or non-temporal alike: writes mixed into a read stream cost several times their
+        // bytes.)
+        float* tr = skinny_b + k * kPitch + (threadIdx.x >> 6) * (16 * kTrPitch);
+        const int orow_l = lane >> 2, ocol_l = 4 * (lane & 3);
+        const int64_t orow = row0 + orow_l;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[t][r];
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                tr[(4 * g + r) * kTrPitch + i] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const f32x4v v4 = *reinterpret_cast<const f32x4v*>(tr + orow_l * kTrPitch + ocol_l);
+            const int col = 16 * t + ocol_l;
+            if (orow < m) {
+                float* dst = c + orow * ldc + col;
+                if (c_vec && col + 3 < n) {
+                    *reinterpret_cast<f32x4v*>(dst) = v4;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < n) dst[e] = v4[e];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// true when gemm_skinny_kernel takes the product: few output columns, k in whole 16-k steps, B small enough for
+// LDS, 128-bit rows of A, and rows enough for the streaming form to matter
+static bool skinny_form_fits(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, int trans_b) {
+    const int64_t lds = (k * (n <= 16 ? 20 : 36) + (kBlock / 64) * 16 * 20) * (int64_t)sizeof(float);
+    return !trans_b && n <= 32 && k >= 16 && k % 16 == 0 && lds <= 64 * 1024 && m >= 4096 && lda % 4 == 0 &&
+           ((uintptr_t)a & 15) == 0;
+}
+
+static int launch_skinny(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                         float* c, int64_t ldc, int relu, hipStream_t st) {
+    const int64_t n_groups = ceil_div(m, 16);          // 16-row tiles, one wave each at a time
+    const int nt = n <= 16 ? 1 : 2;
+    const size_t lds = ((size_t)k * (size_t)(16 * nt + 4) + (kBlock / 64) * 16 * 20) * sizeof(float);
+    const int c_vec = (ldc % 4 == 0 && ((uintptr_t)c & 15) == 0) ? 1 : 0;
+    // every block stages B once: few blocks per CU's worth of waves, each walking many row groups
+    const int64_t blocks = std::min<int64_t>(ceil_div(n_groups, kBlock / 64), 256 * 8);
+    if (nt == 1)
+        gemm_skinny_kernel<1><<<(unsigned)blocks, kBlock, lds, st>>>(m, (int)n, (int)k, a, lda, b, ldb, c, ldc, relu, n_groups, c_vec);
+    else
+        gemm_skinny_kernel<2><<<(unsigned)blocks, kBlock, lds, st>>>(m, (int)n, (int)k, a, lda, b, ldb, c, ldc, relu, n_groups, c_vec);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
 // C[k x n] = A^T . G for A [m x k], G [m x n]: the weight gradient dW = H^T . dP of a layer
 // (the gradient of tf.matmul / tf.sparse_tensor_dense_matmul w.r.t. the weights, gcn/models.py:86).
 // The reduction runs over the m nodes, so both operands are read in their storage order: a stage is 32
@@ -1273,6 +1401,7 @@ int gcn_gemm_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, c
     if (!c || (k > 0 && (!a || !b))) return fail(GCN_ERR_BAD_ARG, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int relu = (flags & GCN_RELU) ? 1 : 0;
+    if (skinny_form_fits(m, n, k, a, lda, trans_b)) return launch_skinny(m, n, k, a, lda, b, ldb, c, ldc, relu, st);
     if (n <= 32) return launch_gemm<128, 32>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
     if (n <= 64) return launch_gemm<128, 64>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);
     return launch_gemm<128, 128>(m, n, k, a, lda, b, ldb, trans_b, c, ldc, relu, st);

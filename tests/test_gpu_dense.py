@@ -362,3 +362,39 @@ def test_dropout_store_of_whole_panels_equals_the_guarded_form(oracle, m, n, k, 
         by_rows = sparse.OutDropout(keep, 31, 7, pitch=n + 4, row_ids=ids)
         assert torch.equal(sparse.gemm(a, b_part, trans_b=trans_b, out_dropout=by_rows),
                            sparse.gemm(a, bw, trans_b=trans_b, out_dropout=by_rows)[:, :n])
+
+
+@pytest.mark.parametrize('m,n,k', [(4096, 16, 256), (5000, 16, 16), (70001, 7, 48), (4100, 1, 64), (9000, 17, 32),
+                                   (4097, 32, 448), (6000, 16, 768), (12345, 24, 256)])
+def test_streaming_form_of_the_product_with_few_output_columns(oracle, m, n, k):
+    """n <= 32 with k in whole 16-k steps and at least 4096 rows: the kernel that feeds A from global memory
+    straight into 16 x 16 x 4 MFMAs (hidden -> classes on a large graph).  Against float64, with ReLU, on
+    strided operands and a strided output whose neighbours must stay untouched, and next to the tiled kernel
+    (the same product posed with one row fewer than the streaming form takes... is not possible: the tiled
+    kernel is reached through a k that is not a multiple of 16)."""
+    import torch
+    from gcn_amd import sparse
+    a = _t(oracle.synthetic_dense(m, k, seed=61))
+    b = _t(oracle.synthetic_dense(k, n, seed=62))
+    ref = a.double() @ b.double()
+    scale = float(ref.abs().max())
+    got = sparse.gemm(a, b)
+    assert float((got.double() - ref).abs().max()) <= REL_TOL * scale
+    assert torch.equal(sparse.gemm(a, b), got)                      # deterministic
+    assert torch.equal(sparse.gemm(a, b, relu=True), torch.clamp(got, min=0))
+    # the tiled kernel on the same numbers: k + 4 with four zero columns / rows appended
+    a_pad = torch.zeros((m, k + 4), device='cuda')
+    a_pad[:, :k] = a
+    b_pad = torch.zeros((k + 4, n), device='cuda')
+    b_pad[:k] = b
+    tiled = sparse.gemm(a_pad, b_pad)
+    assert float((got - tiled).abs().max()) <= 4e-6 * scale
+    # strided A (row pitch k + 8, start 4 floats in), strided B, strided C
+    a_wide = torch.zeros((m, k + 8), device='cuda')
+    a_wide[:, 4:4 + k] = a
+    b_wide = torch.zeros((k, n + 3), device='cuda')
+    b_wide[:, 1:1 + n] = b
+    c_wide = torch.full((m, n + 5), -3.0, device='cuda')
+    sparse.gemm(a_wide[:, 4:4 + k], b_wide[:, 1:1 + n], out=c_wide[:, 2:2 + n])
+    assert torch.equal(c_wide[:, 2:2 + n], got)
+    assert bool((c_wide[:, :2] == -3.0).all()) and bool((c_wide[:, 2 + n:] == -3.0).all())
