@@ -1026,8 +1026,8 @@ __global__ __launch_bounds__(kBlock) void gemm_skinny_kernel(int64_t m, int n, i
         // per lane, 1 KiB contiguous per instruction when C's rows are 16 floats.  (What the output costs is not
         // its shape: on 2^24 x 256 x 16 the kernel takes 2.85 ms with the stores removed or confined to the L2 --
         // 6.1 TB/s, the rate of a pure read sweep -- and 3.65 ms with the 1 GB of C going to HBM, in 64-byte
-        // pieces, in whole lines or non-temporal alike: writes mixed into a read stream cost several times their
-        // bytes.)
+        // pieces, in whole lines or non-temporal alike; a bare sweep that reads 16 GiB and writes 1 GiB beside it
+        // takes 3.55-3.69 ms too: that is the rate of this traffic mix.)
         float* tr = skinny_b + k * kPitch + (threadIdx.x >> 6) * (16 * kTrPitch);
         const int orow_l = lane >> 2, ocol_l = 4 * (lane & 3);
         const int64_t orow = row0 + orow_l;

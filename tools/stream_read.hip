@@ -45,6 +45,32 @@ __global__ __launch_bounds__(256) void halves_kernel(const float* __restrict__ t
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = acc[0];
 }
 
+// A read sweep with a thin write stream beside it: a wave reads GROUP consecutive 16 KiB tiles (16 rows of
+// 1 KiB) and then writes GROUP KiB contiguous (64 bytes per row read), the traffic of a product with 256 input and
+// 16 output columns.
+template <int GROUP>
+__global__ __launch_bounds__(256) void read_write_kernel(const float* __restrict__ t, int64_t n_tiles, float* __restrict__ w) {
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int lane = threadIdx.x & 63;
+    for (int64_t grp = wave; grp * GROUP < n_tiles; grp += n_waves) {
+        f32x4 acc[GROUP];
+#pragma unroll
+        for (int q = 0; q < GROUP; ++q) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(t + (grp * GROUP + q) * 4096) + lane;
+            f32x4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[u * 64];
+            acc[q] = v[0];
+#pragma unroll
+            for (int u = 1; u < 16; ++u) acc[q] += v[u];
+        }
+#pragma unroll
+        for (int q = 0; q < GROUP; ++q)
+            reinterpret_cast<f32x4*>(w + (grp * GROUP + q) * 256)[lane] = acc[q];
+    }
+}
+
 template <typename F>
 static void timed(const char* name, size_t bytes, F launch) {
     hipEvent_t e0, e1;
@@ -80,6 +106,18 @@ int main() {
         timed(name, bytes, [&] { rows_kernel<16><<<blocks, 256>>>((const f32x4*)t, n_vec, out); });
         snprintf(name, sizeof name, "16 rows x 64 B per instruction, %d blocks", blocks);
         timed(name, bytes, [&] { halves_kernel<<<blocks, 256>>>(t, (int64_t)(bytes / 16384), out); });
+    }
+    float* w;
+    CHECK(hipMalloc(&w, bytes / 16));
+    const int64_t n_tiles = bytes / 16384;
+    for (int blocks : {256 * 4, 256 * 8}) {
+        char name[96];
+        snprintf(name, sizeof name, "read 16 KiB, write 1 KiB per wave, %d blocks", blocks);
+        timed(name, bytes + bytes / 16, [&] { read_write_kernel<1><<<blocks, 256>>>(t, n_tiles, w); });
+        snprintf(name, sizeof name, "read 64 KiB, write 4 KiB per wave, %d blocks", blocks);
+        timed(name, bytes + bytes / 16, [&] { read_write_kernel<4><<<blocks, 256>>>(t, n_tiles, w); });
+        snprintf(name, sizeof name, "read 256 KiB, write 16 KiB per wave, %d blocks", blocks);
+        timed(name, bytes + bytes / 16, [&] { read_write_kernel<16><<<blocks, 256>>>(t, n_tiles, w); });
     }
     return 0;
 }
