@@ -848,6 +848,249 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(int64_t n_long
 }
 
 // ------------------------------------------------------------------------------------------------
+// Packed dense operand: rows that are mostly zeros, stored without them.
+//
+// The wide product gathers one row of B per stored entry of A, and the number of 128-byte lines it pulls
+// through the path behind the L2 is what it costs.  The operands a GCN training step gathers are sparse
+// themselves: dropout(X) keeps a fraction keep_prob of the elements (gcn/layers.py:185), and the gradient that
+// the backward product propagates is zero wherever the unit was dropped or inactive (ReLU and dropout of
+// gcn/layers.py:185, 208).  A packed row of f <= 256 columns is
+//     8 x {mask word w: bit c % 32 set iff column 32 w + c is kept; number of kept columns in the words before w}
+//     then the kept values in column order
+// at a row pitch of pack_pitch(f) floats (a multiple of 128 bytes), so a row with k kept values occupies
+// 64 + 4 k bytes: 5 lines instead of 8 at keep_prob 0.5, 3 instead of 8 at a quarter kept.  Lane l of the wave that
+// multiplies a row owns columns 4 l .. 4 l + 3: it reads the pair of its mask word (one 8-byte load, 64 bytes
+// per wave), counts the kept columns before its own (prefix of the pair + popcount under a lane mask), reads
+// 16 bytes of values from that position and hands them to its columns according to its four mask bits.  The
+// sums are the dense kernel's: the same entries in the same order, and a skipped zero would have added a zero.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPackHeader = 16;   // floats: the eight {mask, prefix} pairs
+constexpr int kPackMaxF = 256;
+constexpr int kPackUnroll = 4;    // entries in flight per wave (8 waves per SIMD at 63 registers)
+
+static inline int64_t pack_pitch(int64_t f) { return (kPackHeader + f + 31) / 32 * 32; }
+
+// One wave per row.  DROP: the row is dropout(x) -- x / keep_prob where the decision of element
+// index_offset + row * pitch + col says keep, as dropout_kernel computes it -- and what is packed are its
+// nonzeros; otherwise the nonzeros of x itself.
+template <bool DROP>
+__global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f, const float* __restrict__ x,
+                                                          int64_t ldx, int x_vec, float* __restrict__ packed,
+                                                          int64_t ldpk, OutDrop od) {
+    if (DROP && od.stream_offset) od.key = stream_key(od.seed, od.stream_id + *od.stream_offset);
+    const int lane = threadIdx.x & 63;
+    const int w = lane >> 3, sh = 4 * (lane & 7), col = 4 * lane;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t row = wave; row < n_rows; row += n_waves) {
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* src = x + row * ldx + col;
+        if (x_vec && col + 3 < f) {
+            load_vec<4>(src, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < f) v[e] = src[e];
+        }
+        if (DROP) {
+            const uint64_t id = (uint64_t)(od.index_offset + row * od.pitch + col);
+            const bool one_hash = (id & 3) == 0;
+            const uint64_t h4 = one_hash ? decision_hash(od.key, id) : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint64_t h = one_hash ? h4 : decision_hash(od.key, id + e);
+                const float scaled = __fdiv_rn(v[e], od.keep_prob);
+                v[e] = (col + e < f && keep_field(h, id + e, od.threshold)) ? scaled : 0.0f;
+            }
+        }
+        uint32_t nib = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nib |= (v[e] != 0.0f ? 1u : 0u) << e;
+        uint32_t word = nib << sh;                        // OR over the 8 lanes that share a mask word
+        word |= (uint32_t)__shfl_xor((int)word, 1);
+        word |= (uint32_t)__shfl_xor((int)word, 2);
+        word |= (uint32_t)__shfl_xor((int)word, 4);
+        const uint32_t count = (uint32_t)__popc(word);
+        uint32_t before = 0;                              // kept columns in the words before this lane's
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const uint32_t t = (uint32_t)__shfl((int)count, 8 * q);
+            if (q < w) before += t;
+        }
+        float* dst = packed + row * ldpk;
+        if ((lane & 7) == 0) reinterpret_cast<uint2*>(dst)[w] = make_uint2(word, before);
+        float* out = dst + kPackHeader + before + __popc(word & ((1u << sh) - 1u));
+        int at = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if ((nib >> e) & 1u) out[at++] = v[e];
+    }
+}
+
+// dense row-major copy of a packed matrix (tests and callers that need the expanded form)
+__global__ __launch_bounds__(kBlock) void unpack_rows_kernel(int64_t n_rows, int f, const float* __restrict__ packed,
+                                                            int64_t ldpk, float* __restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 63;
+    const int w = lane >> 3, sh = 4 * (lane & 7), col = 4 * lane;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t row = wave; row < n_rows; row += n_waves) {
+        const float* src = packed + row * ldpk;
+        const uint2 h = reinterpret_cast<const uint2*>(src)[w];
+        const float* in = src + kPackHeader + h.y + __popc(h.x & ((1u << sh) - 1u));
+        const uint32_t nib = (h.x >> sh) & 15u;
+        int at = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = ((nib >> e) & 1u) ? in[at++] : 0.0f;
+            if (col + e < f) y[row * ldy + col + e] = v;
+        }
+    }
+}
+
+// acc += sum over entries k0..k1-1 (in order) of a_k * (row col_k of the packed operand, this lane's four columns).
+// Per entry a lane reads the pair of its mask word (8 bytes; 64 bytes per wave), counts the kept columns before its
+// own, reads 16 bytes of values from that (4-byte aligned) position and hands them to its columns by its four mask
+// bits: column e takes value number (kept columns among 0..e-1) if its bit is set, zero otherwise -- selects by bit
+// masks, no branch (a branch per entry would also let the compiler sink each load next to its use: one exposed
+// latency per entry).  Three stages in flight: the (index, value) pairs two batches ahead, the mask pairs of the next
+// batch, and the values of this one.  Slots past the end of the range (clamped repeats of the last entry) get an
+// empty mask and add zeros.
+// Measured on the scale-24 graph, f = 256: 61 ms at half the columns kept and 57 ms at a quarter, against 74 ms for
+// the dense operand -- not the 5/8 and 3/8 the line counts promise: the vector ALU is 80 % busy (53 instructions per
+// entry) and the address unit 87 % (unaligned 16-byte reads that overlap between neighbouring lanes).  Aligned
+// reads by the first kept/4 lanes straight into LDS and a read-back per column cut both but chain two more
+// latencies per batch: 64-69 ms.
+template <int U>
+__device__ __forceinline__ void accumulate_packed(int64_t k0, int64_t k1, const int32_t* __restrict__ indices,
+                                                  const float* __restrict__ vals, const float* __restrict__ pk,
+                                                  uint32_t ldpk, int w, int sh, float (&acc)[4]) {
+    if (k0 >= k1) return;
+    const int64_t k_last = k1 - 1;
+    const uint32_t below = (1u << sh) - 1u;
+    uint32_t c0[U], c1[U];
+    float a0[U], a1[U];
+    uint2 h[U];
+    auto entries = [&](int64_t kb, uint32_t (&c)[U], float (&a)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
+            c[u] = (uint32_t)indices[ku];
+            a[u] = vals[ku];
+        }
+    };
+    // row base in scalar registers (the column is the same in every lane) + a 32-bit byte offset per lane
+    auto row_of = [&](uint32_t c) { return reinterpret_cast<const char*>(pk + (uint64_t)c * (uint64_t)ldpk); };
+    auto headers = [&](const uint32_t (&c)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) h[u] = *reinterpret_cast<const uint2*>(row_of(c[u]) + (uint32_t)(8 * w));
+    };
+    entries(k0, c0, a0);
+    entries(k0 + U, c1, a1);
+    headers(c0);
+    for (int64_t k = k0;; k += U) {
+        float4 v[U];
+        uint32_t nib[U];
+        float a_now[U];
+        const char* from[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t at = h[u].y + (uint32_t)__popc(h[u].x & below);
+            nib[u] = (h[u].x >> sh) & 15u;
+            from[u] = row_of(c0[u]) + (uint32_t)((at + kPackHeader) * 4u);
+            a_now[u] = a0[u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_memcpy(&v[u], from[u], 16);   // 4-byte aligned: the hardware takes it
+        __builtin_amdgcn_sched_barrier(0);
+        headers(c1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            c0[u] = c1[u];
+            a0[u] = a1[u];
+        }
+        entries(k + 2 * U, c1, a1);
+        // everything above is in flight before anything below waits for it
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t rem = k1 - k;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t m = (u < rem) ? nib[u] : 0u;
+            const uint32_t m0 = 0u - (m & 1u), m1 = 0u - ((m >> 1) & 1u), m2 = 0u - ((m >> 2) & 1u),
+                           m3 = 0u - ((m >> 3) & 1u);
+            const uint32_t any01 = m0 | m1, both01 = m0 & m1;
+            const uint32_t ge1 = any01 | m2, ge2 = both01 | (any01 & m2), ge3 = both01 & m2;   // kept among 0..2
+            const uint32_t v0 = __float_as_uint(v[u].x), v1 = __float_as_uint(v[u].y), v2 = __float_as_uint(v[u].z),
+                           v3 = __float_as_uint(v[u].w);
+            auto pick = [](uint32_t mask, uint32_t yes, uint32_t no) { return (yes & mask) | (no & ~mask); };
+            const uint32_t s1 = pick(m0, v1, v0);                       // value number (b0)
+            const uint32_t s2 = pick(both01, v2, pick(any01, v1, v0));  // value number (b0 + b1)
+            const uint32_t s3 = pick(ge3, v3, pick(ge2, v2, pick(ge1, v1, v0)));
+            const float x0 = __uint_as_float(v0 & m0), x1 = __uint_as_float(s1 & m1), x2 = __uint_as_float(s2 & m2),
+                        x3 = __uint_as_float(s3 & m3);
+            acc[0] = __fadd_rn(acc[0], __fmul_rn(a_now[u], x0));
+            acc[1] = __fadd_rn(acc[1], __fmul_rn(a_now[u], x1));
+            acc[2] = __fadd_rn(acc[2], __fmul_rn(a_now[u], x2));
+            acc[3] = __fadd_rn(acc[3], __fmul_rn(a_now[u], x3));
+        }
+        if (rem <= U) break;
+    }
+}
+
+// The product with a packed operand, one launch: chunk blocks first, strip blocks after them, a wave per row
+// or chunk (f <= 256: four columns per lane), the split threshold of the wide dense product.
+template <int U>
+__global__ __launch_bounds__(kBlock, 8) void spmm_packed_kernel(PlanView pv, const int64_t* __restrict__ indptr,
+                                                            const int32_t* __restrict__ indices,
+                                                            const float* __restrict__ vals, int f,
+                                                            const float* __restrict__ pk, uint32_t ldpk,
+                                                            float* __restrict__ c, int64_t ldc, int c_vec,
+                                                            float* __restrict__ part, int64_t ldp, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int w = lane >> 3, sh = 4 * (lane & 7), col = 4 * lane;
+    const int64_t block = blockIdx.x;
+    // the wave's number as a scalar: its rows, their entry ranges and the entries themselves (the same in every
+    // lane) then live in scalar registers and come through scalar loads
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    auto store = [&](float* dst, bool vec, const float (&acc)[4], bool act) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (act && !(acc[e] > 0.0f)) ? 0.0f : acc[e];
+        if (vec && col + 3 < f) {
+            store_vec<4>(dst + col, o);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < f) dst[col + e] = o[e];
+        }
+    };
+    if (block < pv.chunk_blocks) {
+        const int64_t chunk = block * (kBlock / 64) + wave_in_block;
+        if (chunk >= pv.n_chunks) return;
+        const int li = pv.chunk_long[chunk];
+        const int r = pv.long_row[li];
+        const int64_t k0 = indptr[r] + (chunk - pv.long_chunk[li]) * (int64_t)pv.chunk_len;
+        const int64_t row_end = indptr[r + 1];
+        const int64_t k1 = (k0 + pv.chunk_len < row_end) ? k0 + pv.chunk_len : row_end;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        accumulate_packed<U>(k0, k1, indices, vals, pk, ldpk, w, sh, acc);
+        store(part + chunk * ldp, true, acc, false);      // partial rows: 16-byte aligned, pitch a multiple of 4
+        return;
+    }
+    const int64_t strip = (block - pv.chunk_blocks) * (kBlock / 64) + wave_in_block;
+    if (strip >= pv.n_strips) return;
+    const int r_lo = pv.strip_row[strip], r_hi = pv.strip_row[strip + 1];
+    for (int r = r_lo; r < r_hi; ++r) {
+        const int64_t k0 = indptr[r], k1 = indptr[r + 1];
+        if (k1 - k0 > pv.split) continue;                 // summed chunk-wise
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        accumulate_packed<U>(k0, k1, indices, vals, pk, ldpk, w, sh, acc);
+        store(c + (int64_t)r * ldc, c_vec != 0, acc, relu != 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
 struct SpmmCall {
@@ -1360,6 +1603,119 @@ int gcn_spmm_csr_add_out_dropout_f32(const gcn_spmm_plan* plan, const int64_t* i
     OutDrop od = {stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset, seed, stream_id};
     return spmm_entry<false>(plan, indptr, indices, vals, f, b, ldb, c, ldc, flags, workspace, workspace_bytes, dr,
                              stream, add, ldadd, keep_prob < 1.0f ? &od : nullptr);
+}
+
+int gcn_pack_pitch(int64_t f, int64_t* pitch_floats) {
+    if (!pitch_floats || f < 1 || f > kPackMaxF) return fail(GCN_ERR_BAD_ARG, "a packed row holds 1 to %d columns", kPackMaxF);
+    *pitch_floats = pack_pitch(f);
+    return GCN_OK;
+}
+
+static int pack_entry(bool drop, int64_t n_rows, int64_t f, const float* x, int64_t ldx, float* packed, int64_t ldpk,
+                      const OutDrop& od, void* stream) {
+    if (n_rows < 0 || f < 1 || f > kPackMaxF) return fail(GCN_ERR_BAD_ARG, "a packed row holds 1 to %d columns", kPackMaxF);
+    if (ldx < f || ldpk < pack_pitch(f) || ldpk % 32 != 0 || ldpk > INT32_MAX)
+        return fail(GCN_ERR_BAD_ARG, "bad pitch: ldx=%lld, packed pitch %lld (needs a multiple of 32 floats, at least %lld)",
+                    (long long)ldx, (long long)ldpk, (long long)pack_pitch(f));
+    if (n_rows == 0) return GCN_OK;
+    if (!x || !packed) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    if ((uintptr_t)packed & 127) return fail(GCN_ERR_BAD_ARG, "the packed matrix must be 128-byte aligned");
+    const int x_vec = (ldx % 4 == 0 && aligned16(x)) ? 1 : 0;
+    const int64_t blocks = std::min<int64_t>(ceil_div(n_rows, kBlock / 64), (int64_t)1 << 20);
+    if (drop)
+        pack_rows_kernel<true><<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_rows, (int)f, x, ldx, x_vec, packed,
+                                                                                    ldpk, od);
+    else
+        pack_rows_kernel<false><<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_rows, (int)f, x, ldx, x_vec, packed,
+                                                                                     ldpk, od);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_pack_rows_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, float* packed, int64_t ldpk, void* stream) {
+    const OutDrop none = {0, 1.0f, 0, 0, nullptr, 0, 0};
+    return pack_entry(false, n_rows, f, x, ldx, packed, ldpk, none, stream);
+}
+
+int gcn_dropout_pack_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, float keep_prob, uint64_t seed,
+                         uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
+                         float* packed, int64_t ldpk, void* stream) {
+    if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
+    if (index_offset < 0 || pitch < f)
+        return fail(GCN_ERR_BAD_ARG, "bad decision layout: index_offset=%lld pitch=%lld for %lld columns",
+                    (long long)index_offset, (long long)pitch, (long long)f);
+    if (keep_prob == 1.0f) return gcn_pack_rows_f32(n_rows, f, x, ldx, packed, ldpk, stream);
+    const OutDrop od = out_drop_ready(OutDrop{stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset,
+                                              seed, stream_id});
+    return pack_entry(true, n_rows, f, x, ldx, packed, ldpk, od, stream);
+}
+
+int gcn_unpack_rows_f32(int64_t n_rows, int64_t f, const float* packed, int64_t ldpk, float* y, int64_t ldy, void* stream) {
+    if (n_rows < 0 || f < 1 || f > kPackMaxF) return fail(GCN_ERR_BAD_ARG, "a packed row holds 1 to %d columns", kPackMaxF);
+    if (ldy < f || ldpk < pack_pitch(f) || ldpk % 32 != 0) return fail(GCN_ERR_BAD_ARG, "bad pitch");
+    if (n_rows == 0) return GCN_OK;
+    if (!packed || !y) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    if ((uintptr_t)packed & 127) return fail(GCN_ERR_BAD_ARG, "the packed matrix must be 128-byte aligned");
+    const int64_t blocks = std::min<int64_t>(ceil_div(n_rows, kBlock / 64), (int64_t)1 << 20);
+    unpack_rows_kernel<<<(unsigned)blocks, kBlock, 0, (hipStream_t)stream>>>(n_rows, (int)f, packed, ldpk, y, ldy);
+    GCN_LAUNCH_CHECK();
+    return GCN_OK;
+}
+
+int gcn_spmm_csr_packed_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
+                            int64_t f, const float* packed_b, int64_t ldpk, float* c, int64_t ldc, int flags,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!plan) return fail(GCN_ERR_BAD_ARG, "plan is null");
+    if (f < 1 || f > kPackMaxF) return fail(GCN_ERR_BAD_ARG, "a packed row holds 1 to %d columns", kPackMaxF);
+    if (ldc < f || ldpk < pack_pitch(f) || ldpk % 32 != 0 || ldpk > INT32_MAX)
+        return fail(GCN_ERR_BAD_ARG, "bad pitch: ldc=%lld, packed pitch %lld", (long long)ldc, (long long)ldpk);
+    if (!indptr || (plan->nnz > 0 && (!indices || !vals))) return fail(GCN_ERR_BAD_ARG, "null CSR pointer");
+    if (flags & ~GCN_RELU) return fail(GCN_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    if (plan->n_rows == 0) return GCN_OK;
+    if (!c || (plan->nnz > 0 && !packed_b)) return fail(GCN_ERR_BAD_ARG, "null dense pointer");
+    if ((uintptr_t)packed_b & 127) return fail(GCN_ERR_BAD_ARG, "the packed matrix must be 128-byte aligned");
+    const gcn_spmm_plan::LongTable& lt = plan->table[1];          // the cut points of the wide dense product
+    constexpr int kWaves = kBlock / 64;
+    PlanView pv;
+    pv.n_strips = plan->n_strips;
+    pv.nnz = plan->nnz;
+    pv.n_chunks = lt.n_chunks;
+    pv.chunk_blocks = ceil_div(lt.n_chunks, kWaves);
+    pv.split = plan->split[1];
+    pv.chunk_len = plan->chunk_len ? plan->chunk_len : pv.split;
+    pv.hot_cols = 0;
+    pv.lds_hub_rows = 0;
+    pv.strip_row = plan->strip_row;
+    pv.chunk_long = lt.chunk_long;
+    pv.long_row = lt.long_row;
+    pv.long_chunk = lt.long_chunk;
+    float* part = nullptr;
+    const int64_t ldp = partial_ld(f);
+    if (lt.n_chunks > 0) {
+        const size_t need = (size_t)lt.n_chunks * (size_t)ldp * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return fail(GCN_ERR_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        if (!aligned16(workspace)) return fail(GCN_ERR_BAD_ARG, "workspace must be 16-byte aligned");
+        part = (float*)workspace;
+    }
+    const int64_t grid = pv.chunk_blocks + ceil_div(plan->n_strips, kWaves);
+    if (grid > INT32_MAX) return fail(GCN_ERR_BAD_ARG, "matrix too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    const int relu = (flags & GCN_RELU) ? 1 : 0;
+    const int c_vec = (ldc % 4 == 0 && aligned16(c)) ? 1 : 0;
+    if (plan->timing) GCN_HIP_TRY(hipEventRecord(plan->ev[0], st));
+    spmm_packed_kernel<kPackUnroll><<<(unsigned)grid, kBlock, 0, st>>>(pv, indptr, indices, vals, (int)f, packed_b,
+                                                                      (uint32_t)ldpk, c, ldc, c_vec, part, ldp, relu);
+    GCN_LAUNCH_CHECK();
+    if (plan->timing) GCN_HIP_TRY(hipEventRecord(plan->ev[1], st));
+    if (lt.n_chunks > 0) {
+        const OutDrop none = {0, 1.0f, 0, 0, nullptr, 0, 0};
+        spmm_long_reduce_kernel<<<(unsigned)ceil_div(lt.n_long, kWaves), kBlock, 0, st>>>(
+            lt.n_long, lt.long_row, lt.long_chunk, f, part, ldp, c, ldc, relu, c_vec, nullptr, 0, none);
+        GCN_LAUNCH_CHECK();
+    }
+    if (plan->timing) GCN_HIP_TRY(hipEventRecord(plan->ev[2], st));
+    return GCN_OK;
 }
 
 }  // extern "C"

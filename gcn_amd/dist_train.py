@@ -105,8 +105,10 @@ class ShardedGCN(object):
 
     def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
                  seed=0, group=None, chunks=4, aggregate_first=None, receptive_field=True, labelled_logits_only=True,
-                 reorder=None, own_first=False):
-        """``own_first`` (False, True or 'auto'): handed to every HaloPlan of the model (see dist.HaloPlan): the
+                 reorder=None, own_first=False, packed_operands=True):
+        """``packed_operands``: False keeps every product on dense operands (see _aggregate_dropped_input).
+
+        ``own_first`` (False, True or 'auto'): handed to every HaloPlan of the model (see dist.HaloPlan): the
         entries that read a rank's own rows are multiplied while the exchange is on the links.
 
         ``reorder`` ('degree', 'hubs' or ('hubs', K); one rank only): the model works on the graph with its
@@ -127,6 +129,8 @@ class ShardedGCN(object):
         # ranges of feature columns an exchange is pipelined over: a count, or a tuple of width shares
         self.chunks = chunks if shard.world > 1 else 1
         self.own_first = own_first
+        # one GPU: dropout(X) goes to the first layer's product in packed form (see _aggregate_dropped_input)
+        self.packed_operands, self._pack_buffer = bool(packed_operands), None
         self.plan = HaloPlan(shard, group=group, own_first=own_first)
         self.dropout, self.wd, self.seed = float(dropout), float(weight_decay), int(seed)
         sizes = [f_in] + list(layer_size) + [n_classes]
@@ -225,16 +229,31 @@ class ShardedGCN(object):
         drop = keep < 1.0
         w0, w1 = self.weights
         h = x_local
-        if drop:                                                     # the input has no gradient: a plain pass
-            h = sparse.dropout(h, keep, self.seed, self.step_count * 64,
-                               index_offset=self.shard.row_begin * h.shape[1])
-        s = _product(plans['wide'], h, False, self.chunks)
+        s = self._aggregate_dropped_input(plans['wide'], h, keep)
         next_drop = None
         if drop:
             next_drop = sparse.OutDropout(keep, self.seed, self.step_count * 64 + 1, 0, w0.shape[1], plans['row_ids'])
         h = _AggregatedFirstLayerFn.apply(s, w0, True, next_drop)
         p = _GatedGemmFn.apply(h, w1, keep) if drop else _GemmFn.apply(h, w1)
         return _HaloSpmmFn.apply(plans['logits'], p, False, self.chunks, True, None, plans['back'])
+
+    def _aggregate_dropped_input(self, plan, x_local, keep):
+        """S = A . dropout(X) for the first layer taken as (A . X') . W0.  The features take no gradient, so their
+        dropout is a plain pass -- and on one GPU, for 128 < f <= 256, not even that: dropout(X) is written in
+        packed form (its kept values only, sparse.dropout_pack) and the product gathers the packed rows, fewer lines
+        per row than the dense ones (same decisions, same values, same sums)."""
+        f = x_local.shape[1]
+        offset = self.shard.row_begin * f
+        if keep >= 1.0:
+            return _product(plan, x_local, False, self.chunks)
+        if self.packed_operands and plan._identity and 128 < f <= sparse.PackedRows.MAX_F:
+            hit = self._pack_buffer
+            if hit is None or hit.n_rows != x_local.shape[0] or hit.f != f or hit.data.device != x_local.device:
+                hit = self._pack_buffer = sparse.PackedRows.empty(x_local.shape[0], f, x_local.device)
+            packed = sparse.dropout_pack(x_local, keep, self.seed, self.step_count * 64, index_offset=offset, out=hit)
+            return sparse.spmm_packed(plan.compact, packed)
+        h = sparse.dropout(x_local, keep, self.seed, self.step_count * 64, index_offset=offset)
+        return _product(plan, h, False, self.chunks)
 
     def _in_model_order(self, t):
         """A per-node tensor given in the dataset's order, in the order the model works in."""
@@ -266,10 +285,7 @@ class ShardedGCN(object):
                 next_drop = sparse.OutDropout(keep, self.seed, self.step_count * 64 + li + 1,
                                               self.shard.row_begin * w.shape[1])
             if li == 0 and self.aggregate_first:
-                if drop:                                   # the input has no gradient: a plain pass
-                    h = sparse.dropout(h, keep, self.seed, self.step_count * 64,
-                                       index_offset=self.shard.row_begin * h.shape[1])
-                s = _product(self.plan, h, False, self.chunks)
+                s = self._aggregate_dropped_input(self.plan, h, keep)
                 h = _AggregatedFirstLayerFn.apply(s, w, li != last, next_drop)
                 continue
             if drop and li == 0 and not h.requires_grad:

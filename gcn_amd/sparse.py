@@ -545,6 +545,84 @@ def spmm_add(a, b, d, relu=False, out=None, wide_split=False, out_dropout=None):
     return out
 
 
+class PackedRows(object):
+    """A dense [n_rows x f] matrix (f <= 256) without its zeros: per row eight {mask word, kept columns before it}
+    pairs and the kept values in column order, at a pitch of ``ld`` floats (``data``: [n_rows x ld] float32).  What
+    ``spmm_packed`` gathers instead of dense rows: 64 + 4 k bytes for a row with k kept values."""
+
+    MAX_F = 256
+
+    def __init__(self, n_rows, f, data):
+        self.n_rows, self.f, self.data = int(n_rows), int(f), data
+
+    @property
+    def ld(self):
+        return self.data.shape[1]
+
+    @staticmethod
+    def pitch(f):
+        out = ctypes.c_int64()
+        _lib.call('gcn_pack_pitch', int(f), ctypes.byref(out))
+        return int(out.value)
+
+    @classmethod
+    def empty(cls, n_rows, f, device):
+        # torch's allocator returns 512-byte aligned blocks; rows are a multiple of 128 bytes
+        return cls(n_rows, f, torch.empty((n_rows, cls.pitch(f)), dtype=torch.float32, device=device))
+
+    def dense(self, out=None):
+        """The expanded matrix."""
+        if out is None:
+            out = torch.empty((self.n_rows, self.f), dtype=torch.float32, device=self.data.device)
+        _lib.call('gcn_unpack_rows_f32', self.n_rows, self.f, _p(self.data), self.ld, _p(out), _ld(out), _stream())
+        return out
+
+    def kept(self):
+        """Number of stored values per row (int64)."""
+        words = self.data[:, :16:2].contiguous().view(torch.int32)
+        total = torch.zeros(self.n_rows, dtype=torch.int64, device=self.data.device)
+        for b in range(32):
+            total += ((words >> b) & 1).sum(dim=1)
+        return total
+
+
+def pack_rows(x, out=None):
+    """The nonzeros of ``x`` [n x f], f <= 256, as PackedRows."""
+    _require_cuda(x)
+    x = _rowmajor(x)
+    n, f = x.shape
+    out = out or PackedRows.empty(n, f, x.device)
+    _lib.call('gcn_pack_rows_f32', n, f, _p(x), _ld(x), _p(out.data), out.ld, _stream())
+    return out
+
+
+def dropout_pack(x, keep_prob, seed, stream_id, index_offset=0, out=None):
+    """``dropout(x, keep_prob, seed, stream_id, index_offset=...)`` as PackedRows, the dense result never written."""
+    _require_cuda(x)
+    x = _rowmajor(x)
+    n, f = x.shape
+    out = out or PackedRows.empty(n, f, x.device)
+    _lib.call('gcn_dropout_pack_f32', n, f, _p(x), _ld(x), float(keep_prob), int(seed), int(stream_id),
+              _p(_stream_offset), int(index_offset), f, _p(out.data), out.ld, _stream())
+    return out
+
+
+def spmm_packed(a, b, relu=False, out=None):
+    """``a @ b.dense()`` for a PackedRows ``b``: the values of ``spmm(a, b.dense())`` (long rows cut as the wide
+    product cuts them), gathering packed rows."""
+    if b.n_rows != a.n_cols:
+        raise ValueError('shape mismatch: %s @ packed [%d x %d]' % (a.shape, b.n_rows, b.f))
+    f = b.f
+    if out is None:
+        out = torch.empty((a.n_rows, f), dtype=torch.float32, device=b.data.device)
+    else:
+        _check_out(out, a.n_rows, f)
+    ws, ws_bytes = a.plan.workspace(f, b.data.device)
+    _lib.call('gcn_spmm_csr_packed_f32', a.plan.handle, _p(a.indptr), _p(a.indices), _p(a.values), f, _p(b.data), b.ld,
+              _p(out), _ld(out), _lib.GCN_RELU if relu else 0, _p(ws), ws_bytes, _stream())
+    return out
+
+
 def row_normalize(indptr, vals):
     """Bag-of-words scaling r_inv[row] * value (gcn/utils.py:279-285) of CSR values (float32 or float64)."""
     _require_cuda(indptr, vals)

@@ -312,6 +312,39 @@ int gcn_spmm_csr_add_out_dropout_f32(const gcn_spmm_plan* plan, const int64_t* i
                                      uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset,
                                      int64_t pitch, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Packed dense operand.  The matrices a GCN training step multiplies a support with are sparse themselves:
+ * dropout(X) keeps keep_prob of its elements (gcn/layers.py:185 feeding 198-202), and the gradient the backward
+ * product propagates (the adjoint of gcn/layers.py:202, derived by gcn/models.py:86) is zero wherever the unit was
+ * dropped or inactive.  A packed row of f <= 256 columns is eight {mask word, kept columns in the words before it}
+ * pairs followed by the kept values in column order, at a pitch of gcn_pack_pitch(f) floats; a product that gathers
+ * such rows moves 64 + 4 k bytes per row with k kept values instead of 4 f.  The reference has no counterpart (it
+ * multiplies the dense matrices).
+ *
+ * gcn_pack_pitch: the row pitch, in floats, of the packed form of an f-column matrix (a multiple of 32). */
+int gcn_pack_pitch(int64_t f, int64_t* pitch_floats);
+
+/* packed <- the nonzero elements of x [n_rows x f] (ldx >= f).  `packed` holds n_rows * ldpk floats, ldpk a multiple of
+ * 32 not below gcn_pack_pitch(f), 128-byte aligned. */
+int gcn_pack_rows_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, float* packed, int64_t ldpk, void* stream);
+
+/* packed <- tf.nn.dropout(x, keep_prob) (gcn/layers.py:185) without ever writing the dense result: element (r, c) is
+ * kept iff decision index_offset + r * pitch + c of stream (seed, stream_id) says so and is then x / keep_prob -- the
+ * values and decisions of gcn_dropout_f32.  stream_offset: as for gcn_spmm_csr_dropout_f32. */
+int gcn_dropout_pack_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, float keep_prob, uint64_t seed,
+                         uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
+                         float* packed, int64_t ldpk, void* stream);
+
+/* y [n_rows x f] <- the dense form of a packed matrix (zeros where nothing was kept). */
+int gcn_unpack_rows_f32(int64_t n_rows, int64_t f, const float* packed, int64_t ldpk, float* y, int64_t ldy, void* stream);
+
+/* C[n_rows x f] = A . B for B in packed form [n_cols rows, pitch ldpk]: gcn_spmm_csr_f32 (gcn/layers.py:202) on an
+ * operand that is mostly zeros.  Same entries in the same order as the dense product, long rows cut where the wide
+ * dense product cuts them: the same values (a skipped zero would have added a zero).  flags: GCN_RELU.  Workspace
+ * as for gcn_spmm_csr_f32. */
+int gcn_spmm_csr_packed_f32(const gcn_spmm_plan* plan, const int64_t* indptr, const int32_t* indices, const float* vals,
+                            int64_t f, const float* packed_b, int64_t ldpk, float* c, int64_t ldc, int flags,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Dense pieces of the layer.                                                 *
  * ------------------------------------------------------------------------- */

@@ -462,3 +462,33 @@ def test_sharded_model_on_a_relabelled_graph_follows_the_plain_one(reorder, form
     with pytest.raises(ValueError, match='one rank'):
         two = gdist.RowShardedCSR(n, n, 0, n // 2, shard.local, 0, 2)
         ShardedGCN(two, f_in, [hidden], classes, reorder='degree')
+
+
+@pytest.mark.parametrize('receptive_field', [True, False])
+def test_first_layer_on_packed_dropped_features_changes_nothing(receptive_field):
+    """One GPU, 256 input features, aggregate-first: dropout(X) written in packed form and gathered packed
+    (ShardedGCN(packed_operands=True), the default) against the dense pass and the dense product -- the same
+    decisions, the same values, the same sums: identical losses and weights after 3 Adam steps."""
+    from gcn_amd import dist as gdist, sparse
+    from gcn_amd.dist_train import ShardedGCN
+    scale, f_in, hidden, classes = 13, 256, 256, 8
+    n = 1 << scale
+    indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    x = sparse.synthetic_dense(n, f_in, seed=7)
+    gen = torch.Generator().manual_seed(5)
+    cls = torch.randint(0, classes, (n,), generator=gen)
+    labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32).cuda()
+    mask = (torch.rand(n, generator=gen) < 0.05).to(torch.int32).cuda()
+    runs = []
+    for packed in (True, False):
+        shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, 1)
+        model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9,
+                           receptive_field=receptive_field, packed_operands=packed)
+        assert model.aggregate_first
+        losses = [float(model.train_step(x, labels, mask)) for _ in range(3)]
+        assert (model._pack_buffer is not None) == packed
+        runs.append((losses, [w.detach().clone() for w in model.weights]))
+    assert runs[0][0] == runs[1][0]
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))

@@ -1,0 +1,103 @@
+"""The packed dense operand (rows stored without their zeros) and the product that gathers it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sparse_dense(n, f, density, seed):
+    import torch
+    from gcn_amd import sparse
+    x = sparse.synthetic_dense(n, f, seed=seed)
+    pick = sparse.synthetic_dense(n, f, seed=seed + 100)
+    lo, hi = float(pick.min()), float(pick.max())
+    return torch.where(pick < lo + density * (hi - lo), x, torch.zeros_like(x))
+
+
+@pytest.mark.parametrize('f', [256, 192, 130, 33, 7])
+@pytest.mark.parametrize('density', [0.0, 0.25, 0.5, 1.0])
+def test_pack_and_unpack_round_trip(f, density):
+    import torch
+    from gcn_amd import sparse
+    n = 3001
+    x = _sparse_dense(n, f, density, seed=5)
+    if density == 1.0:
+        x = torch.where(x == 0, torch.ones_like(x), x)
+    wide = torch.zeros((n, f + 3), device='cuda')             # a strided, unaligned source
+    wide[:, 1:1 + f] = x
+    for src in (x, wide[:, 1:1 + f]):
+        packed = sparse.pack_rows(src)
+        assert packed.ld % 32 == 0 and packed.ld >= 16 + f
+        assert torch.equal(packed.dense(), x)
+        assert torch.equal(packed.kept(), (x != 0).sum(dim=1))
+    # the header of a row: eight {mask, kept columns in the words before} pairs
+    head = packed.data[:, :16].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+    bits = (x != 0).cpu().numpy()
+    for w in range(8):
+        cols = bits[:, 32 * w:32 * w + 32]
+        want = (cols * (1 << np.arange(cols.shape[1], dtype=np.int64))).sum(axis=1)
+        assert np.array_equal(head[:, 2 * w], want)
+        assert np.array_equal(head[:, 2 * w + 1], bits[:, :32 * w].sum(axis=1))
+
+
+@pytest.mark.parametrize('keep_prob', [0.5, 0.9, 0.1])
+@pytest.mark.parametrize('f', [256, 100])
+def test_dropout_straight_into_the_packed_form(oracle, f, keep_prob):
+    import torch
+    from gcn_amd import sparse
+    n, offset = 2050, 12 * f
+    x = sparse.synthetic_dense(n, f, seed=8)
+    want = sparse.dropout(x, keep_prob, 77, 3, index_offset=offset)
+    ref, _ = oracle.dense_dropout(x.cpu().numpy(), keep_prob, oracle.stream_key(77, 3), index_offset=offset)
+    assert np.array_equal(want.cpu().numpy(), ref)
+    packed = sparse.dropout_pack(x, keep_prob, 77, 3, index_offset=offset)
+    assert torch.equal(packed.dense(), want)
+
+
+@pytest.mark.parametrize('f', [256, 160, 64])
+@pytest.mark.parametrize('density', [0.5, 0.25, 0.02])
+def test_product_with_a_packed_operand_gives_the_dense_product(oracle, f, density):
+    """Scale-17 R-MAT A_hat (rows of every length, chunked hub rows included) times a matrix that is mostly zeros:
+    the packed product against the dense kernel on the expanded matrix -- equal as numbers everywhere (the dense
+    kernel cuts its long rows at the same entries when told to split as the wide product does) -- and against the
+    CPU loop on the rows it sums serially."""
+    import torch
+    from gcn_amd import sparse
+    scale = 17
+    n = 1 << scale
+    indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    a = sparse.DeviceCSR(n, n, indptr, indices, vals)
+    b = _sparse_dense(n, f, density, seed=21)
+    packed = sparse.pack_rows(b)
+    got = sparse.spmm_packed(a, packed)
+    dense = sparse.spmm(a, b, wide_split=True)
+    assert torch.equal(got, dense)
+    assert torch.equal(sparse.spmm_packed(a, packed, relu=True), torch.clamp(dense, min=0))
+    ip, ix, v = indptr.cpu().numpy(), indices.cpu().numpy(), vals.cpu().numpy()
+    cpu = oracle.spmm_csr(ip, ix, v, b.cpu().numpy(), threads=8)
+    short = np.diff(ip) <= 1024
+    assert short.sum() < n and np.array_equal(got.cpu().numpy()[short], cpu[short])
+    # a strided output
+    wide = torch.full((n, f + 8), -2.0, device='cuda')
+    sparse.spmm_packed(a, packed, out=wide[:, 4:4 + f])
+    assert torch.equal(wide[:, 4:4 + f], dense) and bool((wide[:, :4] == -2.0).all()) and bool((wide[:, 4 + f:] == -2.0).all())
+
+
+def test_small_matrix_and_empty_rows_with_a_packed_operand(oracle):
+    import torch
+    from gcn_amd import sparse
+    from conftest import load_golden
+    fx = load_golden('cora')
+    n = int(fx['n'])
+    a = sparse.DeviceCSR(n, n, torch.as_tensor(fx['ai_indptr'].astype(np.int64)).cuda(),
+                         torch.as_tensor(fx['ai_indices'].astype(np.int32)).cuda(),
+                         torch.as_tensor(fx['hat_values'].astype(np.float32)).cuda())
+    b = _sparse_dense(n, 256, 0.3, seed=4)
+    assert torch.equal(sparse.spmm_packed(a, sparse.pack_rows(b)), sparse.spmm(a, b, wide_split=True))
+    empty = sparse.DeviceCSR(5, n, torch.zeros(6, dtype=torch.int64, device='cuda'),
+                             torch.zeros(0, dtype=torch.int32, device='cuda'), torch.zeros(0, device='cuda'))
+    assert bool((sparse.spmm_packed(empty, sparse.pack_rows(b)) == 0).all())
+    with pytest.raises(ValueError):
+        sparse.pack_rows(torch.zeros((4, 300), device='cuda'))
