@@ -32,7 +32,8 @@ def _product(plan, b_local, relu, chunks, out_dropout=None):
 
 class _HaloSpmmFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, b_local, fuse_relu, chunks, gate_here, out_dropout=None, backward_plan=None):
+    def forward(ctx, plan, b_local, fuse_relu, chunks, gate_here, out_dropout=None, backward_plan=None,
+                pack_grad=False):
         """``gate_here`` False: the backward of the ReLU (and of ``out_dropout``, the next layer's input
         dropout applied in this product's store) is applied by whoever consumes this output -- the
         gradient that arrives here is already the one of the pre-activation.
@@ -40,6 +41,9 @@ class _HaloSpmmFn(torch.autograd.Function):
         outside some rows (the support restricted to those columns: fewer entries, a smaller exchange)."""
         out = _product(plan, b_local, fuse_relu, chunks, out_dropout)
         ctx.plan, ctx.gate, ctx.chunks = backward_plan or plan, fuse_relu and gate_here, chunks
+        # ``pack_grad``: the gradient that arrives is zero wherever the unit was inactive or dropped; on one GPU
+        # and for 128 < f <= 256 the backward product gathers it in packed form (same sums, fewer lines per row)
+        ctx.pack_grad = bool(pack_grad) and fuse_relu
         if ctx.gate:
             ctx.save_for_backward(out)
         return out
@@ -50,8 +54,13 @@ class _HaloSpmmFn(torch.autograd.Function):
             out, = ctx.saved_tensors
             grad = sparse.dropout(grad, 1.0, 0, 0, gate=out)
         plan = ctx.plan
+        grad = grad.contiguous()
         # symmetric support: rows of A^T are rows of A
-        return None, _product(plan, grad.contiguous(), False, ctx.chunks), None, None, None, None, None
+        if ctx.pack_grad and plan._identity and 128 < grad.shape[1] <= sparse.PackedRows.MAX_F:
+            out = sparse.spmm_packed(plan.compact, sparse.pack_rows(grad))
+        else:
+            out = _product(plan, grad, False, ctx.chunks)
+        return None, out, None, None, None, None, None, None
 
 
 class _ShardDropoutFn(torch.autograd.Function):
@@ -302,7 +311,8 @@ class ShardedGCN(object):
             if li == last and logit_plans is not None:     # a training step: labelled rows forward, labelled columns backward
                 h = _HaloSpmmFn.apply(logit_plans[0], p, False, self.chunks, not drop, None, logit_plans[1])
             else:
-                h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop)
+                h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop, None,
+                                      self.packed_operands)
         return h
 
     def _local_mask_mean(self, mask_local):

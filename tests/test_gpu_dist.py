@@ -464,11 +464,12 @@ def test_sharded_model_on_a_relabelled_graph_follows_the_plain_one(reorder, form
         ShardedGCN(two, f_in, [hidden], classes, reorder='degree')
 
 
-@pytest.mark.parametrize('receptive_field', [True, False])
-def test_first_layer_on_packed_dropped_features_changes_nothing(receptive_field):
-    """One GPU, 256 input features, aggregate-first: dropout(X) written in packed form and gathered packed
-    (ShardedGCN(packed_operands=True), the default) against the dense pass and the dense product -- the same
-    decisions, the same values, the same sums: identical losses and weights after 3 Adam steps."""
+@pytest.mark.parametrize('receptive_field,aggregate_first', [(True, True), (False, True), (False, False)])
+def test_products_on_packed_operands_change_nothing(receptive_field, aggregate_first):
+    """One GPU, 256 input features and hidden units, ShardedGCN(packed_operands=True) (the default) against False.
+    Aggregate-first: dropout(X) is written in packed form and gathered packed.  Reference order: the gradient of
+    the hidden layer, zero wherever the unit was dropped or inactive, is packed before the backward product.  The
+    same decisions, the same values, the same sums: identical losses and weights after 3 Adam steps."""
     from gcn_amd import dist as gdist, sparse
     from gcn_amd.dist_train import ShardedGCN
     scale, f_in, hidden, classes = 13, 256, 256, 8
@@ -485,10 +486,9 @@ def test_first_layer_on_packed_dropped_features_changes_nothing(receptive_field)
     for packed in (True, False):
         shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, 1)
         model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9,
-                           receptive_field=receptive_field, packed_operands=packed)
-        assert model.aggregate_first
+                           receptive_field=receptive_field, aggregate_first=aggregate_first, packed_operands=packed)
         losses = [float(model.train_step(x, labels, mask)) for _ in range(3)]
-        assert (model._pack_buffer is not None) == packed
+        assert (model._pack_buffer is not None) == (packed and aggregate_first)
         runs.append((losses, [w.detach().clone() for w in model.weights]))
     assert runs[0][0] == runs[1][0]
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
