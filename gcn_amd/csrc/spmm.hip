@@ -882,6 +882,8 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f
     const int w = lane >> 3, sh = 4 * (lane & 7), col = 4 * lane;
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+    __shared__ __attribute__((aligned(16))) float stage_all[(kBlock / 64) * 256];
+    float* stage = stage_all + (threadIdx.x >> 6) * 256;
     for (int64_t row = wave; row < n_rows; row += n_waves) {
         float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         const float* src = x + row * ldx + col;
@@ -919,11 +921,26 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f
         }
         float* dst = packed + row * ldpk;
         if ((lane & 7) == 0) reinterpret_cast<uint2*>(dst)[w] = make_uint2(word, before);
-        float* out = dst + kPackHeader + before + __popc(word & ((1u << sh) - 1u));
+        // The kept values go to their packed positions in 1 KiB of LDS private to the wave, and leave it as whole
+        // 16-byte vectors, lane l the values 4 l .. 4 l + 3: contiguous stores instead of up to four scattered
+        // 4-byte stores per lane.
+        float* out = stage + before + __popc(word & ((1u << sh) - 1u));
         int at = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if ((nib >> e) & 1u) out[at++] = v[e];
+        const uint32_t total = (uint32_t)__shfl((int)(before + count), 63);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((uint32_t)(4 * lane) < total) {
+            float o[4];
+            load_vec<4>(stage + 4 * lane, o);
+            store_vec<4>(dst + kPackHeader + 4 * lane, o);     // what lies past the last kept value is never used
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
