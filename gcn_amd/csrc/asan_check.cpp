@@ -67,6 +67,22 @@ static void argument_validation() {
                                             nullptr, 0, 4, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_spmm_csr_add_out_dropout_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, x, 4, x, 4, 0, 0.5f, 1, 1, nullptr,
                                             0, 2, nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
+    {   // packed operand: pitch, shapes, alignment
+        int64_t pitch = 0;
+        EXPECT(gcn_pack_pitch(256, &pitch) == GCN_OK && pitch == 288);
+        EXPECT(gcn_pack_pitch(1, &pitch) == GCN_OK && pitch == 32);
+        EXPECT(gcn_pack_pitch(257, &pitch) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_pack_pitch(16, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_pack_rows_f32(4, 300, x, 300, x, 320, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_pack_rows_f32(4, 16, x, 16, x, 16, nullptr) == GCN_ERR_BAD_ARG);        // pitch below 32
+        EXPECT(gcn_pack_rows_f32(4, 16, nullptr, 16, x, 32, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_pack_rows_f32(0, 16, nullptr, 16, nullptr, 32, nullptr) == GCN_OK);
+        EXPECT(gcn_dropout_pack_f32(4, 16, x, 16, 0.0f, 1, 1, nullptr, 0, 16, x, 32, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_dropout_pack_f32(4, 16, x, 16, 0.5f, 1, 1, nullptr, 0, 8, x, 32, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_unpack_rows_f32(4, 16, x, 32, x, 8, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_spmm_csr_packed_f32(nullptr, ip, nullptr, nullptr, 16, x, 32, x, 16, 0, nullptr, 0, nullptr) ==
+               GCN_ERR_BAD_ARG);
+    }
     EXPECT(gcn_spmm_csr_dropout_f32(nullptr, ip, nullptr, nullptr, nullptr, 4, x, 4, x, 4, 0, 0.0f, 1, 1, nullptr,
                                     nullptr, 0, nullptr) == GCN_ERR_BAD_ARG);
     EXPECT(gcn_spmm_csr_out_dropout_f32(nullptr, ip, nullptr, nullptr, 4, x, 4, x, 4, 0, 0.5f, 1, 1, nullptr, 0, 2,
