@@ -978,42 +978,65 @@ __global__ __launch_bounds__(kBlock) void unpack_rows_kernel(int64_t n_rows, int
 // entry) and the address unit 87 % (unaligned 16-byte reads that overlap between neighbouring lanes).  Aligned
 // reads by the first kept/4 lanes straight into LDS and a read-back per column cut both but chain two more
 // latencies per batch: 64-69 ms.
+// (mask & yes) | (~mask & no) in one instruction; written as an expression the compiler turns it into a compare
+// and a conditional move
+__device__ __forceinline__ uint32_t bit_select(uint32_t mask, uint32_t yes, uint32_t no) {
+    uint32_t out;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(out) : "v"(mask), "v"(yes), "v"(no));
+    return out;
+}
+
 template <int U>
 __device__ __forceinline__ void accumulate_packed(int64_t k0, int64_t k1, const int32_t* __restrict__ indices,
                                                   const float* __restrict__ vals, const float* __restrict__ pk,
                                                   uint32_t ldpk, int w, int sh, float (&acc)[4]) {
     if (k0 >= k1) return;
-    const int64_t k_last = k1 - 1;
+    // a range is a row or a chunk of at most the split threshold: 32-bit offsets from k0, so that the loop control
+    // and the clamps are scalar compares (there is no ordered 64-bit compare on the scalar unit)
+    const int n = (int)(k1 - k0);
+    const int32_t* idx = indices + k0;
+    const float* val = vals + k0;
     const uint32_t below = (1u << sh) - 1u;
     uint32_t c0[U], c1[U];
     float a0[U], a1[U];
-    uint2 h[U];
-    auto entries = [&](int64_t kb, uint32_t (&c)[U], float (&a)[U]) {
+    uint32_t h[U];      // lane l < 16: dword l of the row's sixteen header dwords
+    const int lane4 = 4 * (int)(threadIdx.x & 63);
+    auto entries = [&](int jb, uint32_t (&c)[U], float (&a)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t ku = (kb + u < k_last) ? kb + u : k_last;
-            c[u] = (uint32_t)indices[ku];
-            a[u] = vals[ku];
+            const int ju = min(jb + u, n - 1);
+            c[u] = (uint32_t)idx[ju];
+            a[u] = val[ju];
         }
     };
     // row base in scalar registers (the column is the same in every lane) + a 32-bit byte offset per lane
     auto row_of = [&](uint32_t c) { return reinterpret_cast<const char*>(pk + (uint64_t)c * (uint64_t)ldpk); };
+    // The 64 header bytes of a row are read once, a dword by each of the first 16 lanes: a buffer of 64 bytes, in
+    // which the other lanes' offsets are out of range and cost no access.  (Every lane reading its own pair --
+    // eight distinct pairs -- kept all 16 lane quads of the load busy: 16 of the ~41 cache look-ups per entry.)
     auto headers = [&](const uint32_t (&c)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) h[u] = *reinterpret_cast<const uint2*>(row_of(c[u]) + (uint32_t)(8 * w));
+        for (int u = 0; u < U; ++u) {
+            const __amdgpu_buffer_rsrc_t res =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(row_of(c[u])), 0, 4 * kPackHeader, 0x00020000);
+            h[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(res, lane4, 0, 0);
+        }
     };
-    entries(k0, c0, a0);
-    entries(k0 + U, c1, a1);
+    entries(0, c0, a0);
+    entries(U, c1, a1);
     headers(c0);
-    for (int64_t k = k0;; k += U) {
+    for (int j = 0;; j += U) {
         float4 v[U];
         uint32_t nib[U];
         float a_now[U];
         const char* from[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t at = h[u].y + (uint32_t)__popc(h[u].x & below);
-            nib[u] = (h[u].x >> sh) & 15u;
+            // this lane's pair comes from lanes 2 w and 2 w + 1 through the cross-lane path of the LDS unit
+            const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(8 * w, (int)h[u]);
+            const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute(8 * w + 4, (int)h[u]);
+            const uint32_t at = before + (uint32_t)__popc(word & below);
+            nib[u] = (word >> sh) & ((j + u < n) ? 15u : 0u);
             from[u] = row_of(c0[u]) + (uint32_t)((at + kPackHeader) * 4u);
             a_now[u] = a0[u];
         }
@@ -1027,31 +1050,34 @@ __device__ __forceinline__ void accumulate_packed(int64_t k0, int64_t k1, const 
             c0[u] = c1[u];
             a0[u] = a1[u];
         }
-        entries(k + 2 * U, c1, a1);
+        entries(j + 2 * U, c1, a1);
         // everything above is in flight before anything below waits for it
         __builtin_amdgcn_sched_barrier(0);
-        const int64_t rem = k1 - k;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t m = (u < rem) ? nib[u] : 0u;
-            const uint32_t m0 = 0u - (m & 1u), m1 = 0u - ((m >> 1) & 1u), m2 = 0u - ((m >> 2) & 1u),
-                           m3 = 0u - ((m >> 3) & 1u);
-            const uint32_t any01 = m0 | m1, both01 = m0 & m1;
-            const uint32_t ge1 = any01 | m2, ge2 = both01 | (any01 & m2), ge3 = both01 & m2;   // kept among 0..2
-            const uint32_t v0 = __float_as_uint(v[u].x), v1 = __float_as_uint(v[u].y), v2 = __float_as_uint(v[u].z),
-                           v3 = __float_as_uint(v[u].w);
-            auto pick = [](uint32_t mask, uint32_t yes, uint32_t no) { return (yes & mask) | (no & ~mask); };
-            const uint32_t s1 = pick(m0, v1, v0);                       // value number (b0)
-            const uint32_t s2 = pick(both01, v2, pick(any01, v1, v0));  // value number (b0 + b1)
-            const uint32_t s3 = pick(ge3, v3, pick(ge2, v2, pick(ge1, v1, v0)));
-            const float x0 = __uint_as_float(v0 & m0), x1 = __uint_as_float(s1 & m1), x2 = __uint_as_float(s2 & m2),
-                        x3 = __uint_as_float(s3 & m3);
+            // The values are a queue; column e takes its head if the column's bit is set (zero otherwise), and the
+            // queue then moves up by one: 4 masks, 4 ANDs, 6 bit selects.
+            const int32_t m = (int32_t)nib[u];
+            const uint32_t m0 = (uint32_t)((m << 31) >> 31), m1 = (uint32_t)((m << 30) >> 31),
+                           m2 = (uint32_t)((m << 29) >> 31), m3 = (uint32_t)((m << 28) >> 31);
+            uint32_t q0 = __float_as_uint(v[u].x), q1 = __float_as_uint(v[u].y), q2 = __float_as_uint(v[u].z);
+            const uint32_t q3 = __float_as_uint(v[u].w);
+            const float x0 = __uint_as_float(q0 & m0);
+            q0 = bit_select(m0, q1, q0);
+            q1 = bit_select(m0, q2, q1);
+            q2 = bit_select(m0, q3, q2);
+            const float x1 = __uint_as_float(q0 & m1);
+            q0 = bit_select(m1, q1, q0);
+            q1 = bit_select(m1, q2, q1);
+            const float x2 = __uint_as_float(q0 & m2);
+            q0 = bit_select(m2, q1, q0);
+            const float x3 = __uint_as_float(q0 & m3);
             acc[0] = __fadd_rn(acc[0], __fmul_rn(a_now[u], x0));
             acc[1] = __fadd_rn(acc[1], __fmul_rn(a_now[u], x1));
             acc[2] = __fadd_rn(acc[2], __fmul_rn(a_now[u], x2));
             acc[3] = __fadd_rn(acc[3], __fmul_rn(a_now[u], x3));
         }
-        if (rem <= U) break;
+        if (n - j <= U) break;
     }
 }
 
