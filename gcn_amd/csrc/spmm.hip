@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kBlock) void spmm_long_reduce_kernel(int64_t n_long
 // ------------------------------------------------------------------------------------------------
 constexpr int kPackHeader = 16;   // floats: the eight {mask, prefix} pairs
 constexpr int kPackMaxF = 256;
-constexpr int kPackUnroll = 4;    // entries in flight per wave (8 waves per SIMD at 63 registers)
+constexpr int kPackUnroll = 4;    // entries in flight per wave: 47 registers, 8 waves per SIMD (6 or 8 entries: slower)
 
 static inline int64_t pack_pitch(int64_t f) { return (kPackHeader + f + 31) / 32 * 32; }
 
@@ -973,11 +973,12 @@ __global__ __launch_bounds__(kBlock) void unpack_rows_kernel(int64_t n_rows, int
 // latency per entry).  Three stages in flight: the (index, value) pairs two batches ahead, the mask pairs of the next
 // batch, and the values of this one.  Slots past the end of the range (clamped repeats of the last entry) get an
 // empty mask and add zeros.
-// Measured on the scale-24 graph, f = 256: 61 ms at half the columns kept and 57 ms at a quarter, against 74 ms for
-// the dense operand -- not the 5/8 and 3/8 the line counts promise: the vector ALU is 80 % busy (53 instructions per
-// entry) and the address unit 87 % (unaligned 16-byte reads that overlap between neighbouring lanes).  Aligned
-// reads by the first kept/4 lanes straight into LDS and a read-back per column cut both but chain two more
-// latencies per batch: 64-69 ms.
+// Measured on the scale-24 graph, f = 256: 50.6 ms at half the columns kept and 42.6 ms at a quarter, against 74 ms for
+// the dense operand.  The steps that got it there from 61 / 57 ms, where the vector ALU was 80 % busy (53 instructions
+// per entry) and the address unit 87 %: the hand-out as a queue with one-instruction bit selects (26 instructions per
+// entry), 32-bit loop control, and the header read by 16 lanes instead of 64 (41 -> 24 cache look-ups per entry).
+// Aligned reads by the first kept/4 lanes straight into LDS and a read-back per column chain two more latencies per
+// batch and are bound by the LDS-DMA rate: 64-85 ms.
 // (mask & yes) | (~mask & no) in one instruction; written as an expression the compiler turns it into a compare
 // and a conditional move
 __device__ __forceinline__ uint32_t bit_select(uint32_t mask, uint32_t yes, uint32_t no) {
