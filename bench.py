@@ -217,6 +217,12 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, c
     ref_ms, ref_min, ref_mean, ref_loss, _ = timed(aggregate_first=False, receptive_field=False,
                                                    labelled_logits_only=False)
     ms, ms_min, ms_mean, loss, (aggregated, pruned) = timed()
+    dense = None
+    if group_world == 1:
+        # the same two steps with every product on dense operands (packed_operands=False), for the comparison
+        d_ref = timed(aggregate_first=False, receptive_field=False, labelled_logits_only=False, packed_operands=False)
+        d_new = timed(packed_operands=False)
+        dense = {'reference_order_ms': d_ref[0], 'reference_order_loss': d_ref[3], 'ms': d_new[0], 'loss': d_new[3]}
     reordered = None
     if group_world == 1 and reorder:
         # the same two steps on the graph relabelled hub-first (an integer preprocessing step of this build;
@@ -234,7 +240,11 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, c
             'what': 'forward + backward + Adam, dropout 0.5, one labelled node in 64, rows/%d.  reference_order_ms: '
                     "every layer as A.(X'.W) over all rows (gcn/layers.py:198-202).  ms: first layer as %s%s" % (
                         group_world, "(A.X').W0 (no backward product)" if aggregated else "A.(X'.W0)",
-                        ', hidden rows formed only where a labelled node reads them' if pruned else '')}
+                        ', hidden rows formed only where a labelled node reads them' if pruned else '')
+                    + ('.  One GPU: the operands that are mostly zeros -- dropout(X) in ms, the hidden layer\'s gradient '
+                       'in reference_order_ms -- are gathered in packed form (same values, same sums)'
+                       if group_world == 1 else ''),
+            'dense_operands': dense}
 
 
 def cpu_baseline(a, b_dev, c_dev, row_stride):
@@ -321,6 +331,47 @@ def product_point(label, a, f, steps=10, warmup=2, cpu_rows=0):
             'gather_gbps': gathered / (w_med * 1e-3) / 1e9,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'spmm_rows_kernel',
+                         'kernel_ms': k_med, 'kernel_ms_min': k_min, 'algorithmic_bytes': algo}}
+
+
+def packed_point(a, scale, edge_factor, f, keep, steps=10, warmup=2):
+    """C = a . dropout(X, keep) with dropout(X) written and gathered in packed form (its kept values only): the
+    product of the first layer of a training step.  Algorithmic bytes: the CSR, the packed operand once
+    (64 + 4 kept bytes per row), C once."""
+    from gcn_amd import sparse
+    x = sparse.synthetic_dense(a.n_cols, f, seed=7)
+    packed = sparse.PackedRows.empty(a.n_cols, f, x.device)
+    c = torch.empty((a.n_rows, f), dtype=torch.float32, device=x.device)
+    pack_ms = []
+    for i in range(warmup + 3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sparse.dropout_pack(x, keep, 5, 1, out=packed)
+        torch.cuda.synchronize()
+        if i >= warmup:
+            pack_ms.append((time.perf_counter() - t0) * 1e3)
+    kept = int(packed.kept().sum().item())
+    del x
+    a.plan.set_timing(True)
+    for _ in range(warmup):
+        sparse.spmm_packed(a, packed, out=c)
+    torch.cuda.synchronize()
+    kern = []
+    for _ in range(steps):
+        sparse.spmm_packed(a, packed, out=c)
+        kern.append(a.plan.last_timing()[0])
+    a.plan.set_timing(False)
+    del packed, c
+    torch.cuda.empty_cache()
+    k_med, k_min = _median_min(kern)
+    algo = 8 * a.nnz + 8 * (a.n_rows + 1) + 64 * a.n_cols + 4 * kept + 4 * a.n_rows * f
+    achieved = algo / (k_med * 1e-3) / 1e9
+    return {'workload': 'A_hat . dropout(X, keep %.2f), R-MAT scale %d edge factor %d, F=%d, dropout(X) packed (kept '
+                        'values only)' % (keep, scale, edge_factor, f), 'features': f, 'n_nodes': a.n_rows, 'nnz': a.nnz,
+            'kept_values': kept, 'steps': steps, 'ms_per_product': k_med, 'ms_min': k_min,
+            'pack_ms': float(np.median(pack_ms)),
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'kernel': 'spmm_packed_kernel',
                          'kernel_ms': k_med, 'kernel_ms_min': k_min, 'algorithmic_bytes': algo}}
 
 
@@ -431,6 +482,7 @@ def other_configs(a24, scale, edge_factor, device, with_cpu):
                                  % (scale, edge_factor, f), hubs, f))
     del hubs
     torch.cuda.empty_cache()
+    out.append(packed_point(a24, scale, edge_factor, 256, 0.5))
     # BASELINE config 4: R-MAT 2^22, average degree 32, 512 features
     ip, ix, v = build_graph(22, 16)
     a22 = sparse.DeviceCSR(1 << 22, 1 << 22, ip, ix, v)
