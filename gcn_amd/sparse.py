@@ -607,6 +607,25 @@ def dropout_pack(x, keep_prob, seed, stream_id, index_offset=0, out=None):
     return out
 
 
+GATED_PACK_MAX_K = 16
+
+
+def gemm_gated_pack(a, b, gate, divisor, out=None):
+    """``where(gate > 0, (a @ b.T) / divisor, 0)`` as PackedRows, for ``a`` [m x k], ``b`` [n x k] with n <= 256 and
+    k <= 16: ``gemm_gated(a, b, gate, divisor, trans_b=True)`` without the dense result (equal to it up to the
+    order of the k additions)."""
+    _require_cuda(a, b, gate)
+    a, b, gate = _rowmajor(a), _rowmajor(b), _rowmajor(gate)
+    m, k = a.shape
+    n = b.shape[0]
+    if b.shape[1] != k or tuple(gate.shape) != (m, n):
+        raise ValueError('shape mismatch in gemm_gated_pack')
+    out = out or PackedRows.empty(m, n, a.device)
+    _lib.call('gcn_gemm_gated_pack_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), _p(gate), _ld(gate), float(divisor),
+              _p(out.data), out.ld, _stream())
+    return out
+
+
 def spmm_packed(a, b, relu=False, out=None):
     """``a @ b.dense()`` for a PackedRows ``b``: the values of ``spmm(a, b.dense())`` (long rows cut as the wide
     product cuts them), gathering packed rows."""

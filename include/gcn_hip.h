@@ -334,6 +334,14 @@ int gcn_dropout_pack_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx,
                          uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
                          float* packed, int64_t ldpk, void* stream);
 
+/* packed <- where(gate > 0, (A . B^T) / divisor, 0) for A [m x k], B [n x k] (n <= 256, k <= 16), gate [m x n]: the
+ * gradient of a hidden layer's pre-activation -- gcn_gemm_gated_f32 with trans_b, the backward of tf.matmul
+ * (gcn/layers.py:32-33) with the backward of tf.nn.dropout (gcn/layers.py:185) and of the ReLU (gcn/layers.py:208) --
+ * written in packed form for the backward product (gcn_spmm_csr_packed_f32); the dense gradient is never stored.
+ * Each element is summed over k in ascending order with fused multiply-adds. */
+int gcn_gemm_gated_pack_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                            const float* gate, int64_t ldg, float divisor, float* packed, int64_t ldpk, void* stream);
+
 /* y [n_rows x f] <- the dense form of a packed matrix (zeros where nothing was kept). */
 int gcn_unpack_rows_f32(int64_t n_rows, int64_t f, const float* packed, int64_t ldpk, float* y, int64_t ldy, void* stream);
 

@@ -101,3 +101,34 @@ def test_small_matrix_and_empty_rows_with_a_packed_operand(oracle):
     assert bool((sparse.spmm_packed(empty, sparse.pack_rows(b)) == 0).all())
     with pytest.raises(ValueError):
         sparse.pack_rows(torch.zeros((4, 300), device='cuda'))
+
+
+@pytest.mark.parametrize('m,n,k', [(5000, 256, 16), (3001, 256, 7), (2050, 160, 16), (700, 33, 1)])
+def test_gated_gradient_straight_into_packed_rows(oracle, m, n, k):
+    """where(gate > 0, (A . B^T) / keep, 0) written in packed form: the zero pattern of the gate exactly, the values
+    of gcn_gemm_gated_f32 up to the order of the k additions, and of a float64 evaluation to 1e-6."""
+    import torch
+    from gcn_amd import sparse
+    a = torch.as_tensor(oracle.synthetic_dense(m, k, seed=81)).cuda()
+    b = torch.as_tensor(oracle.synthetic_dense(n, k, seed=82)).cuda()
+    gate = _sparse_dense(m, n, 0.5, seed=83)
+    gate = torch.where(gate > 0, gate, torch.zeros_like(gate))          # zeros and positives, as dropped activations
+    for keep in (0.5, 0.8):
+        packed = sparse.gemm_gated_pack(a, b, gate, keep)
+        got = packed.dense()
+        tiled = sparse.gemm_gated(a, b, gate, keep, trans_b=True)
+        exact = torch.where(gate > 0, (a.double() @ b.double().t()) / keep, torch.zeros((m, n), dtype=torch.float64, device='cuda'))
+        scale = float(exact.abs().max())
+        assert bool((got[gate <= 0] == 0).all())
+        assert float((got.double() - exact).abs().max()) <= 1e-6 * scale
+        assert float((got - tiled).abs().max()) <= 1e-6 * scale
+        assert torch.equal(packed.kept(), (got != 0).sum(dim=1))
+    # strided operands
+    a_wide = torch.zeros((m, k + 3), device='cuda')
+    a_wide[:, 1:1 + k] = a
+    g_wide = torch.zeros((m, n + 5), device='cuda')
+    g_wide[:, 2:2 + n] = gate
+    assert torch.equal(sparse.gemm_gated_pack(a_wide[:, 1:1 + k], b, g_wide[:, 2:2 + n], 0.8).dense(), got)
+    with pytest.raises(ValueError):
+        sparse.gemm_gated_pack(torch.zeros((4, 17), device='cuda'), torch.zeros((8, 17), device='cuda'),
+                               torch.zeros((4, 8), device='cuda'), 0.5)
