@@ -132,3 +132,26 @@ def test_gated_gradient_straight_into_packed_rows(oracle, m, n, k):
     with pytest.raises(ValueError):
         sparse.gemm_gated_pack(torch.zeros((4, 17), device='cuda'), torch.zeros((8, 17), device='cuda'),
                                torch.zeros((4, 8), device='cuda'), 0.5)
+
+
+@pytest.mark.parametrize('f', [255, 130, 33, 4, 1])
+def test_packed_product_at_ragged_widths(oracle, f):
+    """Widths that are not multiples of 4 or of a mask word, on a scale-12 graph with a strided output."""
+    import torch
+    from gcn_amd import sparse
+    scale = 12
+    n = 1 << scale
+    indptr, indices = sparse.rmat_csr(scale, 16, seed=3, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    a = sparse.DeviceCSR(n, n, indptr, indices, vals)
+    b = _sparse_dense(n, f, 0.4, seed=9)
+    ref = oracle.spmm_csr(indptr.cpu().numpy(), indices.cpu().numpy(), vals.cpu().numpy(), b.cpu().numpy())
+    packed = sparse.pack_rows(b)
+    got = sparse.spmm_packed(a, packed)
+    short = np.diff(indptr.cpu().numpy()) <= 1024
+    assert np.array_equal(got.cpu().numpy()[short], ref[short])
+    assert float(np.abs(got.cpu().numpy() - ref).max()) <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+    wide = torch.full((n, f + 3), 7.0, device='cuda')
+    sparse.spmm_packed(a, packed, out=wide[:, 1:1 + f])
+    assert torch.equal(wide[:, 1:1 + f], got) and bool((wide[:, 0] == 7.0).all()) and bool((wide[:, 1 + f:] == 7.0).all())
