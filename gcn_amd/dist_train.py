@@ -181,7 +181,9 @@ class ShardedGCN(object):
         self.receptive_field = bool(receptive_field)
         # a training step computes the last layer's product for labelled rows only (the masked loss reads no
         # other logit) and its backward product over labelled columns only; False: all rows, as the reference does
-        self.labelled_logits_only = bool(labelled_logits_only)
+        # 'backward': all logits forward, but the backward product of the logits still skips the columns of
+        # unlabelled nodes, whose rows of the gradient are exactly zero (the same terms in the same order)
+        self.labelled_logits_only = labelled_logits_only if labelled_logits_only == 'backward' else bool(labelled_logits_only)
         dev = shard.local.device
         g = torch.Generator(device=dev)
         g.manual_seed(self.seed)                       # every rank draws the same replicated weights
@@ -220,7 +222,10 @@ class ShardedGCN(object):
                 everyone = flags
             backward = HaloPlan(shard_with_columns(self.shard, everyone != 0), group=self.group,
                                 own_first=self.own_first)
-            forward = HaloPlan(shard_with_rows(self.shard, flags != 0), group=self.group, own_first=self.own_first)
+            if self.labelled_logits_only == 'backward':       # every logit is formed, as the reference forms them
+                forward = self.plan
+            else:
+                forward = HaloPlan(shard_with_rows(self.shard, flags != 0), group=self.group, own_first=self.own_first)
             hit = (mask_local, (forward, backward))
             self._grad_plans[id(mask_local)] = hit
         return hit[1]

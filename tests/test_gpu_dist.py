@@ -499,3 +499,34 @@ def test_products_on_packed_operands_change_nothing(receptive_field, aggregate_f
         assert np.allclose(runs[0][0], runs[1][0], rtol=2e-6)
         for a, b in zip(runs[0][1], runs[1][1]):
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+def test_all_logits_forward_labelled_columns_backward():
+    """ShardedGCN(labelled_logits_only='backward'): every logit is formed as the reference forms them, and the
+    backward product of the logits runs over the columns of labelled nodes only (the other rows of the gradient
+    are exactly zero).  Against the step that keeps every column: losses and weights equal to rounding (rows cut
+    into chunks are cut elsewhere in the smaller matrix)."""
+    from gcn_amd import dist as gdist, sparse
+    from gcn_amd.dist_train import ShardedGCN
+    scale, f_in, hidden, classes = 13, 64, 128, 8
+    n = 1 << scale
+    indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
+    d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
+    vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
+    x = sparse.synthetic_dense(n, f_in, seed=7)
+    gen = torch.Generator().manual_seed(5)
+    cls = torch.randint(0, classes, (n,), generator=gen)
+    labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32).cuda()
+    mask = (torch.rand(n, generator=gen) < 0.05).to(torch.int32).cuda()
+    runs = []
+    for mode in ('backward', False):
+        shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, 1)
+        model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9,
+                           aggregate_first=False, receptive_field=False, labelled_logits_only=mode)
+        losses = [float(model.train_step(x, labels, mask)) for _ in range(3)]
+        logits = model.forward(x, train=False)
+        assert bool((logits[mask == 0].abs().sum(dim=1) > 0).any())          # unlabelled nodes have logits too
+        runs.append((losses, [w.detach().clone() for w in model.weights]))
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-6)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())

@@ -26,7 +26,9 @@ x = sparse.synthetic_dense(n, f, seed=7)
 rows = torch.arange(n, device='cuda')
 labels = torch.nn.functional.one_hot((rows * 2654435761 >> 7) % classes, classes).to(torch.int32)
 mask = (rows % 64 == 0).to(torch.int32)
-form = dict(aggregate_first=False, receptive_field=False, labelled_logits_only=False) if args.form == 'reference' else {}
+form = (dict(aggregate_first=False, receptive_field=False, labelled_logits_only='backward') if args.form == 'reference'
+        else dict(aggregate_first=False, receptive_field=False, labelled_logits_only=False, packed_operands=False)
+        if args.form == 'dense-reference' else {})
 model = ShardedGCN(shard, f, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=123,
                    reorder=args.reorder, **form)
 for _ in range(args.steps):
