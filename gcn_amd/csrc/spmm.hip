@@ -1064,35 +1064,47 @@ __device__ __forceinline__ void accumulate_packed(int64_t k0, int64_t k1, const 
     const int32_t* idx = indices + k0;
     const float* val = vals + k0;
     const uint32_t below = (1u << sh) - 1u;
+    const uint32_t pitch_bytes = ldpk * 4u;
+    const char* pk_bytes = reinterpret_cast<const char*>(pk);
     uint32_t c0[U], c1[U];
     float a0[U], a1[U];
-    uint32_t h[U];      // lane l < 16: dword l of the row's sixteen header dwords
+    const char* base0[U];   // row bases of the batch whose headers are in h: computed once, used for header and values
+    uint32_t h[U];          // lane l < 16: dword l of the row's sixteen header dwords
     const int lane4 = 4 * (int)(threadIdx.x & 63);
+    // The scalar unit of a CU serves all four SIMDs, one instruction a cycle: what a wave spends there per entry
+    // counts like vector work.  A batch that lies wholly inside the range comes as one multi-dword scalar load per
+    // array (no clamp, no address per entry); the last, partial batch clamps to the last entry; a batch past the end
+    // loads nothing and keeps the previous (valid, masked-out) entries.
     auto entries = [&](int jb, uint32_t (&c)[U], float (&a)[U]) {
+        if (jb + U <= n) {
+            __builtin_memcpy(&c[0], idx + jb, 4 * U);
+            __builtin_memcpy(&a[0], val + jb, 4 * U);
+        } else if (jb < n) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ju = min(jb + u, n - 1);
-            c[u] = (uint32_t)idx[ju];
-            a[u] = val[ju];
+            for (int u = 0; u < U; ++u) {
+                const int ju = min(jb + u, n - 1);
+                c[u] = (uint32_t)idx[ju];
+                a[u] = val[ju];
+            }
         }
     };
-    // row base in scalar registers (the column is the same in every lane) + a 32-bit byte offset per lane
-    auto row_of = [&](uint32_t c) { return reinterpret_cast<const char*>(pk + (uint64_t)c * (uint64_t)ldpk); };
     // The 64 header bytes of a row are read once, a dword by each of the first 16 lanes: a buffer of 64 bytes, in
     // which the other lanes' offsets are out of range and cost no access.  (Every lane reading its own pair --
     // eight distinct pairs -- kept all 16 lane quads of the load busy: 16 of the ~41 cache look-ups per entry.)
     auto headers = [&](const uint32_t (&c)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            base0[u] = pk_bytes + (uint64_t)c[u] * (uint64_t)pitch_bytes;
             const __amdgpu_buffer_rsrc_t res =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(row_of(c[u])), 0, 4 * kPackHeader, 0x00020000);
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0[u]), 0, 4 * kPackHeader, 0x00020000);
             h[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(res, lane4, 0, 0);
         }
     };
-    entries(0, c0, a0);
-    entries(U, c1, a1);
-    headers(c0);
-    for (int j = 0;; j += U) {
+    // One batch: positions from the headers, the value loads, then (while those are in flight) the next batch's
+    // headers and the entries two batches on, then the hand-out.  The last batch of a range may be partial -- its
+    // slots past the end repeat the last entry under an empty mask -- and has nothing to request ahead.
+    auto batch = [&](int j, auto is_last) {
+        constexpr bool kLast = decltype(is_last)::value;
         float4 v[U];
         uint32_t nib[U];
         float a_now[U];
@@ -1103,21 +1115,21 @@ __device__ __forceinline__ void accumulate_packed(int64_t k0, int64_t k1, const 
             const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(8 * w, (int)h[u]);
             const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute(8 * w + 4, (int)h[u]);
             const uint32_t at = before + (uint32_t)__popc(word & below);
-            nib[u] = (word >> sh) & ((j + u < n) ? 15u : 0u);
-            from[u] = row_of(c0[u]) + (uint32_t)((at + kPackHeader) * 4u);
+            // bits 0..3 are this lane's columns (the bits above them are never looked at)
+            nib[u] = kLast ? ((word >> sh) & ((j + u < n) ? 15u : 0u)) : (word >> sh);
+            from[u] = base0[u] + (uint32_t)((at + kPackHeader) * 4u);
             a_now[u] = a0[u];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) __builtin_memcpy(&v[u], from[u], 16);   // 4-byte aligned: the hardware takes it
         __builtin_amdgcn_sched_barrier(0);
-        headers(c1);
+        if (!kLast) {
+            headers(c1);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            c0[u] = c1[u];
-            a0[u] = a1[u];
+            for (int u = 0; u < U; ++u) a0[u] = a1[u];
+            entries(j + 2 * U, c1, a1);
         }
-        entries(j + 2 * U, c1, a1);
         // everything above is in flight before anything below waits for it
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1144,8 +1156,18 @@ __device__ __forceinline__ void accumulate_packed(int64_t k0, int64_t k1, const 
             acc[2] = __fadd_rn(acc[2], __fmul_rn(a_now[u], x2));
             acc[3] = __fadd_rn(acc[3], __fmul_rn(a_now[u], x3));
         }
-        if (n - j <= U) break;
+    };
+    entries(0, c0, a0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        c1[u] = c0[u];
+        a1[u] = a0[u];
     }
+    entries(U, c1, a1);
+    headers(c0);
+    int j = 0;
+    for (; n - j > U; j += U) batch(j, std::false_type{});
+    batch(j, std::true_type{});
 }
 
 // The product with a packed operand, one launch: chunk blocks first, strip blocks after them, a wave per row
