@@ -1053,6 +1053,32 @@ __device__ __forceinline__ uint32_t bit_select(uint32_t mask, uint32_t yes, uint
     return out;
 }
 
+// acc += a * (the lane's four columns of a packed row): `values` are the 16 bytes read at the lane's position in the
+// row's kept values, bits 0..3 of `nib` say which of the lane's columns are kept (higher bits are ignored).  The
+// values are a queue; column e takes its head if the column's bit is set (zero otherwise), and the queue then moves
+// up by one: 4 masks, 4 ANDs, 6 bit selects.
+__device__ __forceinline__ void add_packed_entry(uint32_t nib, const float4& values, float a, float (&acc)[4]) {
+    const int32_t m = (int32_t)nib;
+    const uint32_t m0 = (uint32_t)((m << 31) >> 31), m1 = (uint32_t)((m << 30) >> 31),
+                   m2 = (uint32_t)((m << 29) >> 31), m3 = (uint32_t)((m << 28) >> 31);
+    uint32_t q0 = __float_as_uint(values.x), q1 = __float_as_uint(values.y), q2 = __float_as_uint(values.z);
+    const uint32_t q3 = __float_as_uint(values.w);
+    const float x0 = __uint_as_float(q0 & m0);
+    q0 = bit_select(m0, q1, q0);
+    q1 = bit_select(m0, q2, q1);
+    q2 = bit_select(m0, q3, q2);
+    const float x1 = __uint_as_float(q0 & m1);
+    q0 = bit_select(m1, q1, q0);
+    q1 = bit_select(m1, q2, q1);
+    const float x2 = __uint_as_float(q0 & m2);
+    q0 = bit_select(m2, q1, q0);
+    const float x3 = __uint_as_float(q0 & m3);
+    acc[0] = __fadd_rn(acc[0], __fmul_rn(a, x0));
+    acc[1] = __fadd_rn(acc[1], __fmul_rn(a, x1));
+    acc[2] = __fadd_rn(acc[2], __fmul_rn(a, x2));
+    acc[3] = __fadd_rn(acc[3], __fmul_rn(a, x3));
+}
+
 template <int U>
 __device__ __forceinline__ void accumulate_packed(int64_t k0, int64_t k1, const int32_t* __restrict__ indices,
                                                   const float* __restrict__ vals, const float* __restrict__ pk,
@@ -1134,27 +1160,7 @@ __device__ __forceinline__ void accumulate_packed(int64_t k0, int64_t k1, const 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            // The values are a queue; column e takes its head if the column's bit is set (zero otherwise), and the
-            // queue then moves up by one: 4 masks, 4 ANDs, 6 bit selects.
-            const int32_t m = (int32_t)nib[u];
-            const uint32_t m0 = (uint32_t)((m << 31) >> 31), m1 = (uint32_t)((m << 30) >> 31),
-                           m2 = (uint32_t)((m << 29) >> 31), m3 = (uint32_t)((m << 28) >> 31);
-            uint32_t q0 = __float_as_uint(v[u].x), q1 = __float_as_uint(v[u].y), q2 = __float_as_uint(v[u].z);
-            const uint32_t q3 = __float_as_uint(v[u].w);
-            const float x0 = __uint_as_float(q0 & m0);
-            q0 = bit_select(m0, q1, q0);
-            q1 = bit_select(m0, q2, q1);
-            q2 = bit_select(m0, q3, q2);
-            const float x1 = __uint_as_float(q0 & m1);
-            q0 = bit_select(m1, q1, q0);
-            q1 = bit_select(m1, q2, q1);
-            const float x2 = __uint_as_float(q0 & m2);
-            q0 = bit_select(m2, q1, q0);
-            const float x3 = __uint_as_float(q0 & m3);
-            acc[0] = __fadd_rn(acc[0], __fmul_rn(a_now[u], x0));
-            acc[1] = __fadd_rn(acc[1], __fmul_rn(a_now[u], x1));
-            acc[2] = __fadd_rn(acc[2], __fmul_rn(a_now[u], x2));
-            acc[3] = __fadd_rn(acc[3], __fmul_rn(a_now[u], x3));
+            add_packed_entry(nib[u], v[u], a_now[u], acc);
         }
     };
     entries(0, c0, a0);
@@ -1168,6 +1174,124 @@ __device__ __forceinline__ void accumulate_packed(int64_t k0, int64_t k1, const 
     int j = 0;
     for (; n - j > U; j += U) batch(j, std::false_type{});
     batch(j, std::true_type{});
+}
+
+// Rows r .. r_hi - 1 of a strip as ONE stream of entries: their entries are contiguous in the CSR arrays, so the
+// three stages above keep running across row boundaries instead of draining and refilling once per row (a row of
+// this graph has 32 entries on average = 8 batches, and a refill is three dependent memory latencies).  A batch that
+// lies inside the current row adds its entries without a test; a batch in which a row ends takes the copy of the
+// code that tests before every entry, stores the finished row and moves on.  The stream ends after row r_hi - 1 or
+// in front of a row longer than the split threshold (those are summed chunk-wise); the row it stopped at is
+// returned.  Row r itself must not be longer than the threshold.  Same entries, same order of additions per row as
+// accumulate_packed.
+template <int U, typename Store>
+__device__ __forceinline__ int stream_packed(int r, const int r_hi, const int64_t* __restrict__ indptr,
+                                             const int32_t* __restrict__ indices, const float* __restrict__ vals,
+                                             const float* __restrict__ pk, uint32_t ldpk, int split, int w, int sh,
+                                             Store&& store) {
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t k0 = indptr[r];
+    int64_t end_abs = indptr[r + 1];                      // end of the current row
+    int64_t next_abs = indptr[min(r + 2, r_hi)];          // end of the row after it, requested a row early
+    // entries the requests may touch: up to the end of the strip's rows (a long row among them only bounds the
+    // look-ahead further out; what is added is decided by the row ends below)
+    const int n = (int)min(indptr[r_hi] - k0, (int64_t)(1 << 30));
+    if (n == 0) {                                          // nothing but empty rows
+        for (; r < r_hi; ++r) store(r, acc);
+        return r_hi;
+    }
+    int row_end = (int)(end_abs - k0);
+    const int32_t* idx = indices + k0;
+    const float* val = vals + k0;
+    const uint32_t below = (1u << sh) - 1u;
+    const uint32_t pitch_bytes = ldpk * 4u;
+    const char* pk_bytes = reinterpret_cast<const char*>(pk);
+    uint32_t c0[U], c1[U];
+    float a0[U], a1[U];
+    const char* base0[U];
+    uint32_t h[U];
+    const int lane4 = 4 * (int)(threadIdx.x & 63);
+    auto entries = [&](int jb, uint32_t (&c)[U], float (&a)[U]) {
+        if (jb + U <= n) {
+            __builtin_memcpy(&c[0], idx + jb, 4 * U);
+            __builtin_memcpy(&a[0], val + jb, 4 * U);
+        } else if (jb < n) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ju = min(jb + u, n - 1);
+                c[u] = (uint32_t)idx[ju];
+                a[u] = val[ju];
+            }
+        }
+    };
+    auto headers = [&](const uint32_t (&c)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            base0[u] = pk_bytes + (uint64_t)c[u] * (uint64_t)pitch_bytes;
+            const __amdgpu_buffer_rsrc_t res =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0[u]), 0, 4 * kPackHeader, 0x00020000);
+            h[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(res, lane4, 0, 0);
+        }
+    };
+    // the current row is complete: store it and make the next one current; true when the stream ends here
+    auto next_row = [&]() -> bool {
+        store(r, acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = 0.0f;
+        ++r;
+        if (r == r_hi) return true;
+        const int64_t len = next_abs - end_abs;
+        if (len > (int64_t)split) return true;
+        row_end += (int)len;
+        end_abs = next_abs;
+        next_abs = indptr[min(r + 2, r_hi)];
+        return false;
+    };
+    entries(0, c0, a0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        c1[u] = c0[u];
+        a1[u] = a0[u];
+    }
+    entries(U, c1, a1);
+    headers(c0);
+    for (int j = 0;; j += U) {
+        float4 v[U];
+        uint32_t nib[U];
+        float a_now[U];
+        const char* from[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(8 * w, (int)h[u]);
+            const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute(8 * w + 4, (int)h[u]);
+            const uint32_t at = before + (uint32_t)__popc(word & below);
+            nib[u] = word >> sh;
+            from[u] = base0[u] + (uint32_t)((at + kPackHeader) * 4u);
+            a_now[u] = a0[u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_memcpy(&v[u], from[u], 16);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + U < n) {                                   // there is a next batch
+            headers(c1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) a0[u] = a1[u];
+            entries(j + 2 * U, c1, a1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + U <= row_end) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) add_packed_entry(nib[u], v[u], a_now[u], acc);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                while (j + u == row_end)                   // `while`: rows without entries end where they start
+                    if (next_row()) return r;
+                add_packed_entry(nib[u], v[u], a_now[u], acc);
+            }
+        }
+    }
 }
 
 // The product with a packed operand, one launch: chunk blocks first, strip blocks after them, a wave per row
@@ -1213,12 +1337,16 @@ __global__ __launch_bounds__(kBlock, 8) void spmm_packed_kernel(PlanView pv, con
     const int64_t strip = (block - pv.chunk_blocks) * (kBlock / 64) + wave_in_block;
     if (strip >= pv.n_strips) return;
     const int r_lo = pv.strip_row[strip], r_hi = pv.strip_row[strip + 1];
-    for (int r = r_lo; r < r_hi; ++r) {
-        const int64_t k0 = indptr[r], k1 = indptr[r + 1];
-        if (k1 - k0 > pv.split) continue;                 // summed chunk-wise
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        accumulate_packed<U>(k0, k1, indices, vals, pk, ldpk, w, sh, acc);
-        store(c + (int64_t)r * ldc, c_vec != 0, acc, relu != 0);
+    int r = r_lo;
+    while (r < r_hi) {
+        if (indptr[r + 1] - indptr[r] > pv.split) {       // summed chunk-wise
+            ++r;
+            continue;
+        }
+        r = stream_packed<U>(r, r_hi, indptr, indices, vals, pk, ldpk, pv.split, w, sh,
+                             [&](int row, const float (&acc)[4]) {
+                                 store(c + (int64_t)row * ldc, c_vec != 0, acc, relu != 0);
+                             });
     }
 }
 

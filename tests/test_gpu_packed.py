@@ -155,3 +155,32 @@ def test_packed_product_at_ragged_widths(oracle, f):
     wide = torch.full((n, f + 3), 7.0, device='cuda')
     sparse.spmm_packed(a, packed, out=wide[:, 1:1 + f])
     assert torch.equal(wide[:, 1:1 + f], got) and bool((wide[:, 0] == 7.0).all()) and bool((wide[:, 1 + f:] == 7.0).all())
+
+
+@pytest.mark.parametrize('f', [256, 100])
+def test_packed_product_over_hand_made_row_lengths(oracle, f):
+    """The strip part of the packed product walks consecutive rows as one stream of entries: row ends inside a
+    batch, at a batch boundary, rows without entries (first, last, several in a row), and rows beyond the split
+    threshold (summed chunk-wise) in front of, between and behind short ones.  Every short row bit for bit against
+    the CPU loop, the whole result against the dense kernel."""
+    import torch
+    from gcn_amd import sparse
+    rng = np.random.RandomState(17)
+    n_cols = 5000
+    pattern = [0, 0, 1, 4, 8, 3, 0, 5, 12, 1500, 2, 0, 0, 0, 7, 1024, 1025, 1, 4, 4, 4, 2100, 3000, 9, 0, 16, 31, 33,
+               0, 1, 1, 1, 2, 600, 255, 257, 0]
+    lengths = np.array(pattern * 40 + [0, 0], dtype=np.int64)
+    indptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n_cols, size=int(k), replace=False)) for k in lengths]).astype(np.int32)
+    vals = rng.uniform(-1, 1, size=indices.size).astype(np.float32)
+    a = sparse.DeviceCSR(lengths.size, n_cols, torch.as_tensor(indptr).cuda(), torch.as_tensor(indices).cuda(),
+                         torch.as_tensor(vals).cuda())
+    b = _sparse_dense(n_cols, f, 0.3, seed=5)
+    got = sparse.spmm_packed(a, sparse.pack_rows(b))
+    assert torch.equal(got, sparse.spmm(a, b, wide_split=True))
+    assert torch.equal(sparse.spmm_packed(a, sparse.pack_rows(b), relu=True),
+                       torch.clamp(sparse.spmm(a, b, wide_split=True), min=0))
+    cpu = oracle.spmm_csr(indptr, indices, vals, b.cpu().numpy())
+    short = lengths <= 1024
+    assert np.array_equal(got.cpu().numpy()[short], cpu[short])
+    assert bool((got[torch.as_tensor(lengths == 0).cuda()] == 0).all())
