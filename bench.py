@@ -421,6 +421,23 @@ def smoothing_point(device, k=64, f=500, replays=20, with_cpu=True):
                         'kernel_ms': med * 1e-3, 'algorithmic_bytes': algo,
                         'note': 'operand and result (79 MB) stay in the 256 MiB Infinity Cache between steps: '
                                 'this measures launch-to-launch latency and the gather path, not HBM'}}
+    # the same single step with operands from HBM: a 512 MB memset (twice the Infinity Cache) before every
+    # repetition, events around the product alone
+    flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)
+    c = torch.empty_like(x)
+    cold = []
+    for _ in range(replays):
+        flush.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sparse.spmm(a, x, out=c)
+        e1.record()
+        e1.synchronize()
+        cold.append(e0.elapsed_time(e1) * 1e3)
+    out['us_per_step_cold'], out['us_per_step_cold_min'] = _median_min(cold)
+    out['cold'] = ('one step launched on its own after a 512 MB memset: operand, matrix and result come from HBM and '
+                   'the time includes one launch')
+    del flush, c
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         import gcn_oracle as oracle

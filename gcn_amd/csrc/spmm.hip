@@ -1039,10 +1039,13 @@ __global__ __launch_bounds__(kBlock) void unpack_rows_kernel(int64_t n_rows, int
 // latency per entry).  Three stages in flight: the (index, value) pairs two batches ahead, the mask pairs of the next
 // batch, and the values of this one.  Slots past the end of the range (clamped repeats of the last entry) get an
 // empty mask and add zeros.
-// Measured on the scale-24 graph, f = 256: 50.6 ms at half the columns kept and 42.6 ms at a quarter, against 74 ms for
-// the dense operand.  The steps that got it there from 61 / 57 ms, where the vector ALU was 80 % busy (53 instructions
-// per entry) and the address unit 87 %: the hand-out as a queue with one-instruction bit selects (26 instructions per
-// entry), 32-bit loop control, and the header read by 16 lanes instead of 64 (41 -> 24 cache look-ups per entry).
+// Measured on the scale-24 graph, f = 256: 46.6 ms at half the columns kept and 35.2 ms at a quarter, against 74 ms for
+// the dense operand; a packed row costs 5 and 3 lines of 128 bytes there, which bounds the product at 46 and 28 ms.
+// The steps that got it there from 61 / 57 ms, where the vector ALU was 80 % busy (53 instructions per entry) and the
+// address unit 87 %: the hand-out as a queue with one-instruction bit selects (26 instructions per entry), 32-bit loop
+// control, the header read by 16 lanes instead of 64 (41 -> 24 cache look-ups per entry), then the scalar unit (one
+// per CU): whole batches of entries as multi-dword scalar loads, the row base computed once per entry (50.6 / 42.6 ->
+// 46.9 / 36.3), and the rows of a strip walked as one stream (stream_packed below).
 // Aligned reads by the first kept/4 lanes straight into LDS and a read-back per column chain two more latencies per
 // batch and are bound by the LDS-DMA rate: 64-85 ms.
 // (mask & yes) | (~mask & no) in one instruction; written as an expression the compiler turns it into a compare
