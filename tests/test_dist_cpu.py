@@ -143,7 +143,7 @@ def _worker(rank, world, port, result_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])        # 8: the rank count of the full node
 def test_row_sharded_product_equals_single_process(world, oracle, tmp_path):
     port = 29500 + (os.getpid() % 2000) + world
     mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
