@@ -248,7 +248,12 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, c
                        'in reference_order_ms -- are gathered in packed form, and the backward product of the logits in '
                        'reference_order_ms skips the columns of unlabelled nodes, whose gradient rows are zero (same '
                        'values, same sums); dense_operands: the same steps with every operand dense and every column kept'
-                       if group_world == 1 else ''),
+                       if group_world == 1 else
+                       '.  N ranks: in ms the rows of X that a shard reads from other ranks are fetched once, before the '
+                       'timed steps (X is an input that does not change between steps, like the support), and every step '
+                       'drops own and fetched rows locally by their global row numbers into one packed operand: the first '
+                       'layer exchanges nothing; the narrow products of the classes layer exchange their rows every step.  '
+                       'reference_order_ms exchanges the wide rows of X\'.W0 and of the hidden gradient every step'),
             'dense_operands': dense}
 
 

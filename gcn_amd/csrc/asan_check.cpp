@@ -79,6 +79,8 @@ static void argument_validation() {
         EXPECT(gcn_pack_rows_f32(0, 16, nullptr, 16, nullptr, 32, nullptr) == GCN_OK);
         EXPECT(gcn_dropout_pack_f32(4, 16, x, 16, 0.0f, 1, 1, nullptr, 0, 16, x, 32, nullptr) == GCN_ERR_BAD_ARG);
         EXPECT(gcn_dropout_pack_f32(4, 16, x, 16, 0.5f, 1, 1, nullptr, 0, 8, x, 32, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_dropout_pack_rows_f32(4, 16, x, 16, 1.5f, 1, 1, nullptr, 0, 16, nullptr, x, 32, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_dropout_pack_rows_f32(4, 16, x, 16, 0.5f, 1, 1, nullptr, -1, 16, nullptr, x, 32, nullptr) == GCN_ERR_BAD_ARG);
         EXPECT(gcn_unpack_rows_f32(4, 16, x, 32, x, 8, nullptr) == GCN_ERR_BAD_ARG);
         EXPECT(gcn_gemm_gated_pack_f32(4, 16, 17, x, 17, x, 17, x, 16, 0.5f, x, 32, nullptr) == GCN_ERR_BAD_ARG);   // k > 16
         EXPECT(gcn_gemm_gated_pack_f32(4, 300, 8, x, 8, x, 8, x, 300, 0.5f, x, 320, nullptr) == GCN_ERR_BAD_ARG);

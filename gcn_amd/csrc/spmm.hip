@@ -914,7 +914,9 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f
                             ((col + e < f && kk < gs.k) ? 1.0f : 0.0f);      // no branch between the 64 loads
     }
     // a row's elements of x (and, GATED, of a) are requested one row ahead of their use
-    auto fetch = [&](int64_t row, float (&v)[4], float& mine) {
+    auto fetch = [&](int64_t row, float (&v)[4], float& mine, int64_t& drawn) {
+        // the row of the matrix the dropout decisions are drawn for (a scalar load, in flight with the row itself)
+        drawn = (DROP && od.row_ids) ? od.row_ids[row] : row;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 0.0f;
         const float* src = x + row * ldx + col;
@@ -928,13 +930,15 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f
         if (MODE == kPackGated) mine = gs.a[row * gs.lda + min(lane, gs.k - 1)];
     };
     float v_next[4], mine_next = 0.0f;
-    if (wave < n_rows) fetch(wave, v_next, mine_next);
+    int64_t drawn_next = 0;
+    if (wave < n_rows) fetch(wave, v_next, mine_next, drawn_next);
     for (int64_t row = wave; row < n_rows; row += n_waves) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v_next[e];
         const float mine = mine_next;
-        fetch(min(row + n_waves, n_rows - 1), v_next, mine_next);
+        const int64_t drawn = drawn_next;
+        fetch(min(row + n_waves, n_rows - 1), v_next, mine_next, drawn_next);
         if (MODE == kPackGated) {
             // The row of a (at most 64 bytes, new for every row) is read by one vector load, element kk by lane kk,
             // and handed to all lanes through scalar registers.  (As 16 scalar loads it cost 16 misses of the scalar
@@ -961,7 +965,7 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f
             }
         }
         if (DROP) {
-            const uint64_t id = (uint64_t)(od.index_offset + row * od.pitch + col);
+            const uint64_t id = (uint64_t)(od.index_offset + drawn * od.pitch + col);
             const bool one_hash = (id & 3) == 0;
             const uint64_t h4 = one_hash ? decision_hash(od.key, id) : 0;
 #pragma unroll
@@ -1907,17 +1911,25 @@ int gcn_pack_rows_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, fl
     return pack_entry(false, n_rows, f, x, ldx, packed, ldpk, none, stream);
 }
 
-int gcn_dropout_pack_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, float keep_prob, uint64_t seed,
-                         uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
-                         float* packed, int64_t ldpk, void* stream) {
+int gcn_dropout_pack_rows_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, float keep_prob, uint64_t seed,
+                              uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
+                              const int64_t* row_ids, float* packed, int64_t ldpk, void* stream) {
     if (!(keep_prob > 0.0f) || keep_prob > 1.0f) return fail(GCN_ERR_BAD_ARG, "keep_prob must be in (0, 1]");
     if (index_offset < 0 || pitch < f)
         return fail(GCN_ERR_BAD_ARG, "bad decision layout: index_offset=%lld pitch=%lld for %lld columns",
                     (long long)index_offset, (long long)pitch, (long long)f);
     if (keep_prob == 1.0f) return gcn_pack_rows_f32(n_rows, f, x, ldx, packed, ldpk, stream);
-    const OutDrop od = out_drop_ready(OutDrop{stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset,
-                                              seed, stream_id});
+    OutDrop od = out_drop_ready(OutDrop{stream_key(seed, stream_id), keep_prob, index_offset, pitch, stream_offset,
+                                        seed, stream_id});
+    od.row_ids = row_ids;
     return pack_entry(true, n_rows, f, x, ldx, packed, ldpk, od, stream);
+}
+
+int gcn_dropout_pack_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, float keep_prob, uint64_t seed,
+                         uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
+                         float* packed, int64_t ldpk, void* stream) {
+    return gcn_dropout_pack_rows_f32(n_rows, f, x, ldx, keep_prob, seed, stream_id, stream_offset, index_offset, pitch,
+                                     nullptr, packed, ldpk, stream);
 }
 
 int gcn_gemm_gated_pack_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,

@@ -214,6 +214,7 @@ class HaloPlan(object):
         if not self._collective and operand_rows is None:
             # one process, no communicator: the operand holds every column's row, B is the whole operand
             self.compact, self.n_first, self.n_remote, self._identity = local, shard.n_cols, 0, True
+            self.remote_rows = torch.zeros(0, dtype=torch.int64, device=dev)
             self.recv_splits = self.send_splits = [0]
             return
         r0 = shard.rank * per
@@ -256,6 +257,7 @@ class HaloPlan(object):
             if self.send_rows.numel() and int(self.send_rows.min()) < 0:
                 raise ValueError('a requested row is not among operand_rows')
         self.n_remote = int(remote.numel())
+        self.remote_rows = remote.contiguous()       # global row numbers of the received rows, in operand order
         make = csr_factory or sparse.DeviceCSR
         self._identity = False
         in_own = new_cols < self.n_first

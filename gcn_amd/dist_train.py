@@ -147,8 +147,14 @@ class ShardedGCN(object):
 
     def __init__(self, shard, f_in, layer_size, n_classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5,
                  seed=0, group=None, chunks=4, aggregate_first=None, receptive_field=True, labelled_logits_only=True,
-                 reorder=None, own_first=False, packed_operands=True):
+                 reorder=None, own_first=False, packed_operands=True, cache_feature_halo=True):
         """``packed_operands``: False keeps every product on dense operands (see _aggregate_dropped_input).
+
+        ``cache_feature_halo`` (N ranks, first layer aggregated first, packed operands): the rows of the feature
+        matrix that a rank's shard reads from other ranks are fetched ONCE per features tensor and kept; every step
+        drops own and kept rows locally (a row's decisions depend on its global number only), so the step exchanges
+        no wide rows at all (see _aggregate_dropped_input).  The features are an input that does not change between
+        steps, like the support (the reference feeds the same matrix every step, train.py:180-183).
 
         ``own_first`` (False, True or 'auto'): handed to every HaloPlan of the model (see dist.HaloPlan): the
         entries that read a rank's own rows are multiplied while the exchange is on the links.
@@ -173,6 +179,7 @@ class ShardedGCN(object):
         self.own_first = own_first
         # one GPU: dropout(X) goes to the first layer's product in packed form (see _aggregate_dropped_input)
         self.packed_operands, self._pack_buffer = bool(packed_operands), None
+        self.cache_feature_halo, self._feature_halos, self._in_order_twins = bool(cache_feature_halo), {}, {}
         self.plan = HaloPlan(shard, group=group, own_first=own_first)
         self.dropout, self.wd, self.seed = float(dropout), float(weight_decay), int(seed)
         sizes = [f_in] + list(layer_size) + [n_classes]
@@ -261,7 +268,9 @@ class ShardedGCN(object):
                 'rows': r_local,
                 'row_ids': (r_local + self.shard.row_begin).contiguous(),
                 'labelled': lab_rows,
-                'wide': HaloPlan(shard_rows_compacted(self.shard, r_local), group=self.group, own_first=self.own_first),
+                # with the features' halo kept on the rank this product waits for no exchange: nothing to hide
+                'wide': HaloPlan(shard_rows_compacted(self.shard, r_local), group=self.group,
+                                 own_first=False if self._keeps_feature_halo(self.weights[0].shape[0]) else self.own_first),
                 'logits': HaloPlan(shard_rows_compacted(self.shard, lab_rows), group=self.group, operand_rows=r_local,
                                    own_first=self.own_first),
                 'back': HaloPlan(shard_rows_compacted(shard_with_columns(self.shard, everyone), r_local),
@@ -294,13 +303,60 @@ class ShardedGCN(object):
         if keep >= 1.0:
             return _product(plan, x_local, False, self.chunks)
         if self.packed_operands and plan._identity and 128 < f <= sparse.PackedRows.MAX_F:
-            hit = self._pack_buffer
-            if hit is None or hit.n_rows != x_local.shape[0] or hit.f != f or hit.data.device != x_local.device:
-                hit = self._pack_buffer = sparse.PackedRows.empty(x_local.shape[0], f, x_local.device)
-            packed = sparse.dropout_pack(x_local, keep, self.seed, self.step_count * 64, index_offset=offset, out=hit)
+            packed = sparse.dropout_pack(x_local, keep, self.seed, self.step_count * 64, index_offset=offset,
+                                         out=self._packed_rows(x_local.shape[0], f, x_local.device))
+            return sparse.spmm_packed(plan.compact, packed)
+        if self._keeps_feature_halo(f) and not plan._identity:
+            # N ranks: X does not change between steps, so the rows of X this shard reads from other ranks were
+            # fetched once (_feature_halo); own and kept rows are dropped here -- a kept row draws the decisions of
+            # its global row, as its owner draws them -- straight into one packed operand [own rows | kept rows],
+            # which the product gathers in the single-GPU order of additions.  No exchange in the step.
+            plan = self._in_order(plan)
+            halo = self._feature_halo(plan, x_local)
+            n_own, n_kept = x_local.shape[0], halo.shape[0]
+            packed = self._packed_rows(n_own + n_kept, f, x_local.device)
+            sparse.dropout_pack(x_local, keep, self.seed, self.step_count * 64, index_offset=offset,
+                                out=packed.rows(0, n_own))
+            if n_kept:
+                sparse.dropout_pack(halo, keep, self.seed, self.step_count * 64, row_ids=plan.remote_rows,
+                                    out=packed.rows(n_own, n_own + n_kept))
             return sparse.spmm_packed(plan.compact, packed)
         h = sparse.dropout(x_local, keep, self.seed, self.step_count * 64, index_offset=offset)
         return _product(plan, h, False, self.chunks)
+
+    def _packed_rows(self, n_rows, f, device):
+        """The packed operand buffer of the first layer, reused over steps."""
+        hit = self._pack_buffer
+        if hit is None or hit.n_rows != n_rows or hit.f != f or hit.data.device != device:
+            hit = self._pack_buffer = sparse.PackedRows.empty(n_rows, f, device)
+        return hit
+
+    def _keeps_feature_halo(self, f):
+        return (self.cache_feature_halo and self.packed_operands and self.shard.world > 1 and self.dropout > 0.0
+                and 128 < f <= sparse.PackedRows.MAX_F)
+
+    def _in_order(self, plan):
+        """``plan`` itself, or for an own-rows-first plan its twin that keeps the single-GPU order of additions (one
+        matrix over [own rows | received rows]); built once, by every rank at the same point of its first step."""
+        if not plan.own_first:
+            return plan
+        hit = self._in_order_twins.get(id(plan))
+        if hit is None or hit[0] is not plan:
+            hit = (plan, HaloPlan(plan.shard, group=self.group, own_first=False))
+            self._in_order_twins[id(plan)] = hit
+        return hit[1]
+
+    def _feature_halo(self, plan, x_local):
+        """The rows of X that ``plan``'s shard reads from other ranks, [n_remote x f] in operand order: one exchange
+        per (plan, features tensor OBJECT), kept for every later step (a tensor changed in place keeps its copy)."""
+        key = (id(plan), id(x_local))
+        hit = self._feature_halos.get(key)
+        if hit is None or hit[0] is not plan or hit[1] is not x_local:
+            received = plan.exchange(x_local)
+            hit = (plan, x_local, received.clone())
+            plan.drop_buffers()                       # the exchange buffers of this width are not used again
+            self._feature_halos[key] = hit
+        return hit[2]
 
     def _in_model_order(self, t):
         """A per-node tensor given in the dataset's order, in the order the model works in."""

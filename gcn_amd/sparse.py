@@ -570,6 +570,10 @@ class PackedRows(object):
         # torch's allocator returns 512-byte aligned blocks; rows are a multiple of 128 bytes
         return cls(n_rows, f, torch.empty((n_rows, cls.pitch(f)), dtype=torch.float32, device=device))
 
+    def rows(self, begin, end):
+        """Rows begin .. end - 1 as PackedRows over the same memory."""
+        return PackedRows(end - begin, self.f, self.data[begin:end])
+
     def dense(self, out=None):
         """The expanded matrix."""
         if out is None:
@@ -596,14 +600,23 @@ def pack_rows(x, out=None):
     return out
 
 
-def dropout_pack(x, keep_prob, seed, stream_id, index_offset=0, out=None):
-    """``dropout(x, keep_prob, seed, stream_id, index_offset=...)`` as PackedRows, the dense result never written."""
+def dropout_pack(x, keep_prob, seed, stream_id, index_offset=0, out=None, row_ids=None):
+    """``dropout(x, keep_prob, seed, stream_id, index_offset=...)`` as PackedRows, the dense result never written.
+    ``row_ids`` (int64, one per row of ``x``): row r of ``x`` draws the decisions of row ``row_ids[r]`` of the matrix
+    the stream belongs to (rows of another rank's block held here)."""
     _require_cuda(x)
     x = _rowmajor(x)
     n, f = x.shape
     out = out or PackedRows.empty(n, f, x.device)
-    _lib.call('gcn_dropout_pack_f32', n, f, _p(x), _ld(x), float(keep_prob), int(seed), int(stream_id),
-              _p(_stream_offset), int(index_offset), f, _p(out.data), out.ld, _stream())
+    if out.n_rows != n or out.f != f:
+        raise ValueError('the packed output holds %d x %d, the input is %d x %d' % (out.n_rows, out.f, n, f))
+    if row_ids is not None:
+        _require_cuda(row_ids)
+        if row_ids.dtype != torch.int64 or row_ids.numel() != n or not row_ids.is_contiguous():
+            raise ValueError('row_ids must be a contiguous int64 tensor with one entry per row')
+    _lib.call('gcn_dropout_pack_rows_f32', n, f, _p(x), _ld(x), float(keep_prob), int(seed), int(stream_id),
+              _p(_stream_offset), int(index_offset), f, _p(row_ids) if row_ids is not None else None,
+              _p(out.data), out.ld, _stream())
     return out
 
 

@@ -334,6 +334,14 @@ int gcn_dropout_pack_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx,
                          uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
                          float* packed, int64_t ldpk, void* stream);
 
+/* gcn_dropout_pack_f32 for rows that are not consecutive rows of the matrix the decisions are drawn for: row r of x is
+ * row row_ids[r] of that matrix (decision index_offset + row_ids[r] * pitch + c); row_ids null: r itself.  A rank of a
+ * row-partitioned run holds rows of the constant feature matrix (gcn/layers.py:185 drops them anew every step) that
+ * belong to other ranks and drops them as their owner would.  No counterpart in the reference (one process). */
+int gcn_dropout_pack_rows_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx, float keep_prob, uint64_t seed,
+                              uint64_t stream_id, const uint64_t* stream_offset, int64_t index_offset, int64_t pitch,
+                              const int64_t* row_ids, float* packed, int64_t ldpk, void* stream);
+
 /* packed <- where(gate > 0, (A . B^T) / divisor, 0) for A [m x k], B [n x k] (n <= 256, k <= 16), gate [m x n]: the
  * gradient of a hidden layer's pre-activation -- gcn_gemm_gated_f32 with trans_b, the backward of tf.matmul
  * (gcn/layers.py:32-33) with the backward of tf.nn.dropout (gcn/layers.py:185) and of the ReLU (gcn/layers.py:208) --

@@ -251,7 +251,8 @@ def test_rccl_entry_points_of_the_c_abi(tmp_path):
     assert (tmp_path / 'ok').exists()
 
 
-def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first, own_first=False):
+def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first, own_first=False, widths=(32, 128),
+                  tag='', **model_options):
     if world > 1:
         faulthandler.dump_traceback_later(90 if world <= 2 else 150, exit=True)
     sys.path.insert(0, ROOT)
@@ -263,7 +264,7 @@ def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first, 
     try:
         from gcn_amd import dist as gdist, sparse
         from gcn_amd.dist_train import ShardedGCN
-        n, f_in, classes, hidden = 1 << scale, 32, 8, 128
+        n, f_in, classes, hidden = 1 << scale, widths[0], 8, widths[1]
         indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
         d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
         vals = sparse.normalize_values(indptr, indices, None, d, 'sym', want64=False)[1]
@@ -275,13 +276,15 @@ def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first, 
         labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32)[r0:r1].cuda()
         mask = (torch.rand(n, generator=gen) < 0.05).to(torch.int32)[r0:r1].cuda()
         model = ShardedGCN(shard, f_in, [hidden], classes, learning_rate=0.02, weight_decay=5e-4, dropout=0.5, seed=9,
-                           aggregate_first=aggregate_first, own_first=own_first)
+                           aggregate_first=aggregate_first, own_first=own_first, **model_options)
         if own_first != 'auto':                     # 'auto' decides by the share of entries that read own rows
             assert model.plan.own_first == (bool(own_first) and world > 1)
         losses = [float(model.train_step(x, labels, mask)) for _ in range(steps)]
         if rank == 0:
-            np.save(os.path.join(result_dir, 'loss_w%d.npy' % world), np.array(losses))
-            np.save(os.path.join(result_dir, 'w0_w%d.npy' % world), model.weights[0].detach().cpu().numpy())
+            np.save(os.path.join(result_dir, 'loss_w%d%s.npy' % (world, tag)), np.array(losses))
+            np.save(os.path.join(result_dir, 'w0_w%d%s.npy' % (world, tag)), model.weights[0].detach().cpu().numpy())
+            if world > 1 and model_options.get('cache_feature_halo', True) and 128 < f_in <= 256 and aggregate_first:
+                assert len(model._feature_halos) == 1          # one exchange of feature rows, at the first step
     finally:
         if world > 1:
             dist.destroy_process_group()
@@ -319,6 +322,38 @@ def test_eight_rank_training_step_matches_single_gpu(tmp_path):
     w1, w8 = np.load(tmp_path / 'w0_w1.npy'), np.load(tmp_path / 'w0_w8.npy')
     d = np.abs(w1 - w8)
     assert (d <= 1e-5 * np.abs(w1).max()).mean() >= 0.999 and d.max() <= 1e-3 * np.abs(w1).max()
+
+
+@pytest.mark.parametrize('receptive_field', [True, False])
+@pytest.mark.parametrize('own_first', [False, True])
+def test_feature_rows_of_other_ranks_kept_across_steps(tmp_path, receptive_field, own_first):
+    """Wide features (160 columns) on 2 ranks: the rows of X a shard reads from the other rank are fetched once and
+    dropped locally every step, by their global row numbers, into one packed operand.  The first layer's product keeps
+    the single-GPU order of additions either way, so with every other product in order too the losses and weights
+    equal, bit for bit, those of the step that drops its own rows and exchanges them every step; both follow 1 rank."""
+    scale, steps = 13, 3
+    port = 30300 + (os.getpid() % 1000) + (11 if receptive_field else 0) + (23 if own_first else 0)
+    common = dict(widths=(160, 160), receptive_field=receptive_field)
+    _train_worker(0, 1, port, str(tmp_path), scale, steps, True, **common)
+    for tag, cache in (('kept', True), ('sent', False)):
+        mp.start_processes(_train_worker_kw, args=(2, port + (1 if cache else 2), str(tmp_path), scale, steps, own_first,
+                                                   dict(common, tag=tag, cache_feature_halo=cache)),
+                           nprocs=2, join=True, start_method='spawn')
+    l1 = np.load(tmp_path / 'loss_w1.npy')
+    kept, sent = np.load(tmp_path / 'loss_w2kept.npy'), np.load(tmp_path / 'loss_w2sent.npy')
+    assert np.all(np.isfinite(l1)) and np.allclose(l1, kept, rtol=1e-5)
+    wk, ws = np.load(tmp_path / 'w0_w2kept.npy'), np.load(tmp_path / 'w0_w2sent.npy')
+    if not own_first:
+        assert np.array_equal(kept, sent) and np.array_equal(wk, ws)
+    else:
+        assert np.allclose(kept, sent, rtol=1e-5)
+    w1 = np.load(tmp_path / 'w0_w1.npy')
+    d = np.abs(w1 - wk)
+    assert (d <= 1e-5 * np.abs(w1).max()).mean() >= 0.999 and d.max() <= 1e-3 * np.abs(w1).max()
+
+
+def _train_worker_kw(rank, world, port, result_dir, scale, steps, own_first, options):
+    _train_worker(rank, world, port, result_dir, scale, steps, True, own_first, **options)
 
 
 @pytest.mark.parametrize('aggregate_first', [False, True])

@@ -184,3 +184,26 @@ def test_packed_product_over_hand_made_row_lengths(oracle, f):
     short = lengths <= 1024
     assert np.array_equal(got.cpu().numpy()[short], cpu[short])
     assert bool((got[torch.as_tensor(lengths == 0).cuda()] == 0).all())
+
+
+@pytest.mark.parametrize('f', [256, 160])
+def test_dropout_into_packed_rows_by_row_number(oracle, f):
+    """Rows held out of place draw the decisions of the rows they are: packing a subset of the rows of X with their
+    row numbers gives those rows of dropout(X), whatever order they are held in."""
+    import torch
+    from gcn_amd import sparse
+    n = 3000
+    x = torch.as_tensor(oracle.synthetic_dense(n, f, seed=31)).cuda()
+    whole = sparse.dropout(x, 0.5, 7, 3)
+    assert torch.equal(sparse.dropout_pack(x, 0.5, 7, 3).dense(), whole)
+    gen = torch.Generator().manual_seed(2)
+    rows = torch.randperm(n, generator=gen)[:1111].cuda()
+    held = x[rows].contiguous()
+    assert torch.equal(sparse.dropout_pack(held, 0.5, 7, 3, row_ids=rows).dense(), whole[rows])
+    # both parts of one buffer, as a rank packs [own rows | rows of other ranks]
+    buf = sparse.PackedRows.empty(n + rows.numel(), f, x.device)
+    sparse.dropout_pack(x, 0.5, 7, 3, out=buf.rows(0, n))
+    sparse.dropout_pack(held, 0.5, 7, 3, row_ids=rows, out=buf.rows(n, n + rows.numel()))
+    assert torch.equal(buf.dense(), torch.cat([whole, whole[rows]]))
+    with pytest.raises(ValueError):
+        sparse.dropout_pack(held, 0.5, 7, 3, row_ids=rows[:5])
