@@ -218,7 +218,7 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, c
     # products skip what is exactly zero in their operands (the hidden layer's gradient is gathered packed, the
     # gradient of the logits is non-zero at labelled nodes only)
     ref_ms, ref_min, ref_mean, ref_loss, _ = timed(aggregate_first=False, receptive_field=False,
-                                                   labelled_logits_only='backward' if group_world == 1 else False)
+                                                   labelled_logits_only='backward')
     ms, ms_min, ms_mean, loss, (aggregated, pruned) = timed()
     dense = None
     if group_world == 1:

@@ -356,6 +356,27 @@ def _train_worker_kw(rank, world, port, result_dir, scale, steps, own_first, opt
     _train_worker(rank, world, port, result_dir, scale, steps, True, own_first, **options)
 
 
+def test_reference_order_step_with_labelled_columns_backward_on_two_ranks(tmp_path):
+    """The reference's order of operations on 2 ranks in the form the bench line times: every logit formed, the
+    backward product of the logits over the columns of labelled nodes only (a smaller support, a smaller exchange).
+    Against 1 rank in the same form."""
+    scale, steps = 13, 3
+    port = 30500 + (os.getpid() % 1000)
+    form = dict(receptive_field=False, labelled_logits_only='backward')
+    _train_worker(0, 1, port, str(tmp_path), scale, steps, False, **form)
+    mp.start_processes(_train_worker_kw_ref, args=(2, port + 1, str(tmp_path), scale, steps, form), nprocs=2, join=True,
+                       start_method='spawn')
+    l1, l2 = np.load(tmp_path / 'loss_w1.npy'), np.load(tmp_path / 'loss_w2.npy')
+    assert np.all(np.isfinite(l1)) and np.allclose(l1, l2, rtol=1e-5)
+    w1, w2 = np.load(tmp_path / 'w0_w1.npy'), np.load(tmp_path / 'w0_w2.npy')
+    d = np.abs(w1 - w2)
+    assert (d <= 1e-5 * np.abs(w1).max()).mean() >= 0.999 and d.max() <= 1e-3 * np.abs(w1).max()
+
+
+def _train_worker_kw_ref(rank, world, port, result_dir, scale, steps, options):
+    _train_worker(rank, world, port, result_dir, scale, steps, False, False, **options)
+
+
 @pytest.mark.parametrize('aggregate_first', [False, True])
 def test_sharded_training_step_with_own_rows_first(tmp_path, aggregate_first):
     """The same comparison with every plan of the 2-rank model cut into the entries that read own rows (multiplied
