@@ -79,6 +79,7 @@ SIGNATURES = {
     'gcn_dropout_pack_f32': [_i64, _i64, _vp, _i64, _f32, _u64, _u64, _vp, _i64, _i64, _vp, _i64, _vp],
     'gcn_dropout_pack_rows_f32': [_i64, _i64, _vp, _i64, _f32, _u64, _u64, _vp, _i64, _i64, _vp, _vp, _i64, _vp],
     'gcn_gemm_gated_pack_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp],
+    'gcn_gemm_gated_pack_rows_f32': [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _i64, _vp],
     'gcn_unpack_rows_f32': [_i64, _i64, _vp, _i64, _vp, _i64, _vp],
     'gcn_spmm_csr_packed_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _sz, _vp],
     'gcn_spmm_csr_add_out_dropout_f32': [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _u64, _u64,

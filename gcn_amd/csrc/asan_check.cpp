@@ -86,6 +86,9 @@ static void argument_validation() {
         EXPECT(gcn_gemm_gated_pack_f32(4, 300, 8, x, 8, x, 8, x, 300, 0.5f, x, 320, nullptr) == GCN_ERR_BAD_ARG);
         EXPECT(gcn_gemm_gated_pack_f32(4, 16, 8, x, 8, x, 8, x, 16, 0.0f, x, 32, nullptr) == GCN_ERR_BAD_ARG);
         EXPECT(gcn_gemm_gated_pack_f32(4, 16, 8, nullptr, 8, x, 8, x, 16, 0.5f, x, 32, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_gemm_gated_pack_rows_f32(4, 16, 8, x, 8, x, 8, x, 16, 0.5f, nullptr, 2, x, 32, nullptr) == GCN_ERR_BAD_ARG);
+        EXPECT(gcn_gemm_gated_pack_rows_f32(4, 16, 8, x, 8, x, 8, x, 16, 0.5f, (const int64_t*)x, 5, x, 32, nullptr) ==
+               GCN_ERR_BAD_ARG);                                                              // more rows listed than exist
         EXPECT(gcn_spmm_csr_packed_f32(nullptr, ip, nullptr, nullptr, 16, x, 32, x, 16, 0, nullptr, 0, nullptr) ==
                GCN_ERR_BAD_ARG);
     }

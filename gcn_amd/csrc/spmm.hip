@@ -887,6 +887,10 @@ struct GatedSource {
     int k;
     float divisor;
     float inverse;   // 1 / divisor when the divisor is a power of two (the product with it is then the quotient), else 0
+    // may be null: the rows to form (ascending).  Item i of the launch then works on row rows[i] of a, of the gate and
+    // of the packed output (n_rows of the launch counts items); a row number outside [0, m) is skipped.
+    const int64_t* rows;
+    int64_t m;
 };
 
 enum { kPackPlain = 0, kPackDrop = 1, kPackGated = 2 };
@@ -914,9 +918,15 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f
                             ((col + e < f && kk < gs.k) ? 1.0f : 0.0f);      // no branch between the 64 loads
     }
     // a row's elements of x (and, GATED, of a) are requested one row ahead of their use
-    auto fetch = [&](int64_t row, float (&v)[4], float& mine, int64_t& drawn) {
-        // the row of the matrix the dropout decisions are drawn for (a scalar load, in flight with the row itself)
-        drawn = (DROP && od.row_ids) ? od.row_ids[row] : row;
+    auto fetch = [&](int64_t item, float (&v)[4], float& mine, int64_t& drawn) {
+        // DROP: the row of the matrix the dropout decisions are drawn for; GATED with a row list: the row this
+        // item works on (a scalar load; the row's own loads wait for it)
+        drawn = (DROP && od.row_ids) ? od.row_ids[item] : item;
+        int64_t row = item;
+        if (MODE == kPackGated && gs.rows) {
+            drawn = gs.rows[item];
+            row = (drawn >= 0 && drawn < gs.m) ? drawn : 0;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 0.0f;
         const float* src = x + row * ldx + col;
@@ -939,6 +949,11 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f
         const float mine = mine_next;
         const int64_t drawn = drawn_next;
         fetch(min(row + n_waves, n_rows - 1), v_next, mine_next, drawn_next);
+        int64_t out_row = row;
+        if (MODE == kPackGated && gs.rows) {
+            if (drawn < 0 || drawn >= gs.m) continue;          // not a row of the matrix: nothing is written
+            out_row = drawn;
+        }
         if (MODE == kPackGated) {
             // The row of a (at most 64 bytes, new for every row) is read by one vector load, element kk by lane kk,
             // and handed to all lanes through scalar registers.  (As 16 scalar loads it cost 16 misses of the scalar
@@ -989,7 +1004,7 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f
             const uint32_t t = (uint32_t)__shfl((int)count, 8 * q);
             if (q < w) before += t;
         }
-        float* dst = packed + row * ldpk;
+        float* dst = packed + out_row * ldpk;
         if ((lane & 7) == 0) reinterpret_cast<uint2*>(dst)[w] = make_uint2(word, before);
         // The kept values go to their packed positions in 1 KiB of LDS private to the wave, and leave it as whole
         // 16-byte vectors, lane l the values 4 l .. 4 l + 3: contiguous stores instead of up to four scattered
@@ -1011,6 +1026,16 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n_rows, int f
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// every row of a packed matrix made empty: 64 zero bytes per row (its values are then never read)
+__global__ __launch_bounds__(kBlock) void clear_packed_rows_kernel(int64_t n_rows, float* __restrict__ packed, int64_t ldpk) {
+    // four lanes per row, 16 bytes each
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < 4 * n_rows; i += stride) {
+        const float zero[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        store_vec<4>(packed + (i >> 2) * ldpk + 4 * (i & 3), zero);
     }
 }
 
@@ -1889,7 +1914,7 @@ static int pack_entry(bool drop, int64_t n_rows, int64_t f, const float* x, int6
     if ((uintptr_t)packed & 127) return fail(GCN_ERR_BAD_ARG, "the packed matrix must be 128-byte aligned");
     const int x_vec = (ldx % 4 == 0 && aligned16(x)) ? 1 : 0;
     const int64_t blocks = std::min<int64_t>(ceil_div(n_rows, kBlock / 64), (int64_t)1 << 20);
-    const GatedSource none = {nullptr, 0, nullptr, 0, 0, 1.0f, 0.0f};
+    const GatedSource none = {nullptr, 0, nullptr, 0, 0, 1.0f, 0.0f, nullptr, 0};
     if (gated) {
         // every wave first loads its lanes' rows of w (64 values per lane): few waves, each walking many rows
         const int64_t few = std::min<int64_t>(blocks, 256 * 5);
@@ -1932,19 +1957,37 @@ int gcn_dropout_pack_f32(int64_t n_rows, int64_t f, const float* x, int64_t ldx,
                                      nullptr, packed, ldpk, stream);
 }
 
-int gcn_gemm_gated_pack_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
-                            const float* gate, int64_t ldg, float divisor, float* packed, int64_t ldpk, void* stream) {
+int gcn_gemm_gated_pack_rows_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b,
+                                 int64_t ldb, const float* gate, int64_t ldg, float divisor, const int64_t* rows,
+                                 int64_t n_listed, float* packed, int64_t ldpk, void* stream) {
     if (m < 0 || n < 1 || n > kPackMaxF || k < 1 || k > kGatedMaxK)
         return fail(GCN_ERR_BAD_ARG, "the packed gated product takes 1 to %d columns and an inner dimension of 1 to %d",
                     kPackMaxF, kGatedMaxK);
     if (lda < k || ldb < k) return fail(GCN_ERR_BAD_ARG, "leading dimension too small");
     if (!(divisor > 0.0f)) return fail(GCN_ERR_BAD_ARG, "divisor must be positive");
     if (m > 0 && (!a || !b)) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    if (rows ? (n_listed < 0 || n_listed > m) : n_listed != 0)
+        return fail(GCN_ERR_BAD_ARG, "bad row list: %lld rows listed of %lld", (long long)n_listed, (long long)m);
     int exponent = 0;
     const bool power_of_two = std::frexp(divisor, &exponent) == 0.5f && exponent > -100 && exponent < 100;
-    const GatedSource gs = {a, lda, b, ldb, (int)k, divisor, power_of_two ? 1.0f / divisor : 0.0f};
+    const GatedSource gs = {a, lda, b, ldb, (int)k, divisor, power_of_two ? 1.0f / divisor : 0.0f, rows, m};
     const OutDrop none = {0, 1.0f, 0, 0, nullptr, 0, 0};
-    return pack_entry(false, m, n, gate, ldg, packed, ldpk, none, stream, &gs);
+    if (!rows) return pack_entry(false, m, n, gate, ldg, packed, ldpk, none, stream, &gs);
+    // with a row list: every row empty first (64 bytes each), then the listed rows formed
+    if (m == 0) return GCN_OK;
+    if (!gate || !packed) return fail(GCN_ERR_BAD_ARG, "null pointer");
+    if (ldg < n || ldpk < pack_pitch(n) || ldpk % 32 != 0 || ldpk > INT32_MAX || ((uintptr_t)packed & 127))
+        return fail(GCN_ERR_BAD_ARG, "bad pitch or alignment: ldg=%lld, packed pitch %lld", (long long)ldg, (long long)ldpk);
+    const int64_t clear_blocks = std::min<int64_t>(ceil_div(4 * m, kBlock), 256 * 16);
+    clear_packed_rows_kernel<<<(unsigned)clear_blocks, kBlock, 0, (hipStream_t)stream>>>(m, packed, ldpk);
+    GCN_LAUNCH_CHECK();
+    if (n_listed == 0) return GCN_OK;
+    return pack_entry(false, n_listed, n, gate, ldg, packed, ldpk, none, stream, &gs);
+}
+
+int gcn_gemm_gated_pack_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
+                            const float* gate, int64_t ldg, float divisor, float* packed, int64_t ldpk, void* stream) {
+    return gcn_gemm_gated_pack_rows_f32(m, n, k, a, lda, b, ldb, gate, ldg, divisor, nullptr, 0, packed, ldpk, stream);
 }
 
 int gcn_unpack_rows_f32(int64_t n_rows, int64_t f, const float* packed, int64_t ldpk, float* y, int64_t ldy, void* stream) {

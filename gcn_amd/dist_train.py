@@ -78,9 +78,12 @@ class _HiddenThenClassesFn(torch.autograd.Function):
                 and w_next.shape[1] <= sparse.GATED_PACK_MAX_K)
 
     @staticmethod
-    def forward(ctx, plan, p, w_next, keep, out_dropout, chunks):
+    def forward(ctx, plan, p, w_next, keep, out_dropout, chunks, grad_rows=None):
+        """``grad_rows`` (ascending int64 row numbers, or None): the gradient that will arrive is zero in every
+        other row (the backward product of the logits ran over the labelled nodes' columns: only their neighbours
+        get a non-zero row), so the weight gradient sums over these rows only -- the other terms are zeros."""
         h = _product(plan, p, True, chunks, out_dropout)
-        ctx.plan, ctx.keep = plan, keep
+        ctx.plan, ctx.keep, ctx.grad_rows = plan, keep, grad_rows
         ctx.save_for_backward(h, w_next)
         return sparse.gemm(h, w_next)
 
@@ -88,12 +91,25 @@ class _HiddenThenClassesFn(torch.autograd.Function):
     def backward(ctx, grad):
         h, w_next = ctx.saved_tensors
         grad = grad.contiguous()
-        d_w = sparse.gemm_tn(h, grad) if ctx.needs_input_grad[2] else None
+        d_w = None
+        rows = ctx.grad_rows
+        if rows is not None and 2 * rows.numel() >= h.shape[0]:
+            rows = None                      # most rows are live: no gain in listing them
+        if ctx.needs_input_grad[2]:
+            if rows is not None:
+                h_rows = torch.empty((rows.numel(), h.shape[1]), dtype=torch.float32, device=h.device)
+                g_rows = torch.empty((rows.numel(), grad.shape[1]), dtype=torch.float32, device=h.device)
+                sparse.gather_rows(h, rows, h_rows)
+                sparse.gather_rows(grad, rows, g_rows)
+                d_w = sparse.gemm_tn(h_rows, g_rows)
+            else:
+                d_w = sparse.gemm_tn(h, grad)
         d_p = None
         if ctx.needs_input_grad[1]:
-            packed = sparse.gemm_gated_pack(grad, w_next, h, ctx.keep)
+            # rows of the gradient outside ``rows`` are zero: they come out empty without their gate being read
+            packed = sparse.gemm_gated_pack(grad, w_next, h, ctx.keep, rows=rows)
             d_p = sparse.spmm_packed(ctx.plan.compact, packed)     # symmetric support: rows of A^T are rows of A
-        return None, d_p, d_w, None, None, None
+        return None, d_p, d_w, None, None, None, None
 
 
 class _ShardDropoutFn(torch.autograd.Function):
@@ -227,8 +243,11 @@ class ShardedGCN(object):
                 all_gather_rows(everyone, flags.contiguous(), group=self.group)
             else:
                 everyone = flags
-            backward = HaloPlan(shard_with_columns(self.shard, everyone != 0), group=self.group,
-                                own_first=self.own_first)
+            restricted = shard_with_columns(self.shard, everyone != 0)
+            backward = HaloPlan(restricted, group=self.group, own_first=self.own_first)
+            # the rows of that product's output that can be non-zero: the neighbours of labelled nodes
+            lengths = restricted.local.indptr[1:] - restricted.local.indptr[:-1]
+            backward.live_rows = torch.nonzero(lengths > 0).reshape(-1).contiguous()
             if self.labelled_logits_only == 'backward':       # every logit is formed, as the reference forms them
                 forward = self.plan
             else:
@@ -415,7 +434,9 @@ class ShardedGCN(object):
                 h = _HaloSpmmFn.apply(logit_plans[0], p, False, self.chunks, not drop, None, logit_plans[1])
             elif (self.packed_operands and li + 1 == last and p.requires_grad
                   and _HiddenThenClassesFn.usable(self.plan, p, self.weights[li + 1], keep)):
-                ahead = _HiddenThenClassesFn.apply(self.plan, p, self.weights[li + 1], keep, next_drop, self.chunks)
+                ahead = _HiddenThenClassesFn.apply(self.plan, p, self.weights[li + 1], keep, next_drop, self.chunks,
+                                                   getattr(logit_plans[1], 'live_rows', None)
+                                                   if logit_plans is not None else None)
             else:
                 h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop, None,
                                       self.packed_operands)

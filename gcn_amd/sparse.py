@@ -623,19 +623,25 @@ def dropout_pack(x, keep_prob, seed, stream_id, index_offset=0, out=None, row_id
 GATED_PACK_MAX_K = 16
 
 
-def gemm_gated_pack(a, b, gate, divisor, out=None):
+def gemm_gated_pack(a, b, gate, divisor, out=None, rows=None):
     """``where(gate > 0, (a @ b.T) / divisor, 0)`` as PackedRows, for ``a`` [m x k], ``b`` [n x k] with n <= 256 and
     k <= 16: ``gemm_gated(a, b, gate, divisor, trans_b=True)`` without the dense result (equal to it up to the
-    order of the k additions)."""
-    _require_cuda(a, b, gate)
+    order of the k additions).  ``rows`` (ascending int64 row numbers): ``a`` is zero in every other row -- those
+    rows come out empty without being read, only the listed rows are formed."""
+    _require_cuda(a, b, gate, rows)
     a, b, gate = _rowmajor(a), _rowmajor(b), _rowmajor(gate)
     m, k = a.shape
     n = b.shape[0]
     if b.shape[1] != k or tuple(gate.shape) != (m, n):
         raise ValueError('shape mismatch in gemm_gated_pack')
     out = out or PackedRows.empty(m, n, a.device)
-    _lib.call('gcn_gemm_gated_pack_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), _p(gate), _ld(gate), float(divisor),
-              _p(out.data), out.ld, _stream())
+    if rows is not None and (rows.dtype != torch.int64 or not rows.is_contiguous() or rows.dim() != 1):
+        raise ValueError('rows must be a contiguous 1-d int64 tensor')
+    listed = 0 if rows is None else rows.numel()
+    if rows is not None and listed == 0:         # an empty list is still a list (an empty tensor has no address)
+        rows = torch.zeros(1, dtype=torch.int64, device=a.device)
+    _lib.call('gcn_gemm_gated_pack_rows_f32', m, n, k, _p(a), _ld(a), _p(b), _ld(b), _p(gate), _ld(gate),
+              float(divisor), _p(rows), listed, _p(out.data), out.ld, _stream())
     return out
 
 

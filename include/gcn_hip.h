@@ -350,6 +350,16 @@ int gcn_dropout_pack_rows_f32(int64_t n_rows, int64_t f, const float* x, int64_t
 int gcn_gemm_gated_pack_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b, int64_t ldb,
                             const float* gate, int64_t ldg, float divisor, float* packed, int64_t ldpk, void* stream);
 
+/* gcn_gemm_gated_pack_f32 for a gradient known to be zero outside some rows: `rows` (ascending, n_listed of them) are
+ * the rows of A that can hold a nonzero; every row of `packed` is first made empty (64 bytes), then the listed rows are
+ * formed from their rows of A and of the gate.  The gradient that reaches a hidden layer through the backward product
+ * of a masked loss (gcn/metrics.py:85-92) is non-zero at the neighbours of labelled nodes only.  A row number outside
+ * [0, m) is skipped.  rows null (n_listed 0): every row, as gcn_gemm_gated_pack_f32.  No counterpart in the
+ * reference. */
+int gcn_gemm_gated_pack_rows_f32(int64_t m, int64_t n, int64_t k, const float* a, int64_t lda, const float* b,
+                                 int64_t ldb, const float* gate, int64_t ldg, float divisor, const int64_t* rows,
+                                 int64_t n_listed, float* packed, int64_t ldpk, void* stream);
+
 /* y [n_rows x f] <- the dense form of a packed matrix (zeros where nothing was kept). */
 int gcn_unpack_rows_f32(int64_t n_rows, int64_t f, const float* packed, int64_t ldpk, float* y, int64_t ldy, void* stream);
 

@@ -207,3 +207,31 @@ def test_dropout_into_packed_rows_by_row_number(oracle, f):
     assert torch.equal(buf.dense(), torch.cat([whole, whole[rows]]))
     with pytest.raises(ValueError):
         sparse.dropout_pack(held, 0.5, 7, 3, row_ids=rows[:5])
+
+
+def test_gated_gradient_for_listed_rows_only(oracle):
+    """The gradient is zero outside some rows: with those rows listed, the packed result equals the one formed from
+    every row (the unlisted rows come out empty), whatever the buffer held before; out-of-range row numbers are
+    skipped; an empty list empties every row."""
+    import torch
+    from gcn_amd import sparse
+    m, n, k = 6000, 256, 16
+    gen = torch.Generator().manual_seed(3)
+    rows = torch.sort(torch.randperm(m, generator=gen)[:700])[0].cuda()
+    a = torch.zeros((m, k), device='cuda')
+    a[rows] = torch.as_tensor(oracle.synthetic_dense(rows.numel(), k, seed=85)).cuda()
+    b = torch.as_tensor(oracle.synthetic_dense(n, k, seed=86)).cuda()
+    gate = torch.clamp(_sparse_dense(m, n, 0.5, seed=87), min=0)
+    whole = sparse.gemm_gated_pack(a, b, gate, 0.5)
+    stale = sparse.PackedRows.empty(m, n, a.device)
+    stale.data.fill_(float('nan'))
+    listed = sparse.gemm_gated_pack(a, b, gate, 0.5, out=stale, rows=rows)
+    assert torch.equal(listed.dense(), whole.dense()) and torch.equal(listed.kept(), whole.kept())
+    assert bool((listed.kept()[rows] > 0).any())
+    # a row number that is not a row of the matrix is skipped
+    padded = torch.cat([torch.tensor([-1], device='cuda'), rows, torch.tensor([m, m + 5], device='cuda')])
+    with pytest.raises(ValueError):                       # more rows listed than the matrix has
+        sparse.gemm_gated_pack(a, b, gate, 0.5, out=stale, rows=torch.arange(m + 1, device='cuda'))
+    assert torch.equal(sparse.gemm_gated_pack(a, b, gate, 0.5, out=stale, rows=padded).dense(), whole.dense())
+    none = sparse.gemm_gated_pack(a, b, gate, 0.5, out=stale, rows=rows[:0])
+    assert bool((none.dense() == 0).all()) and int(none.kept().sum()) == 0

@@ -41,3 +41,10 @@ dp = sparse.synthetic_dense(n, k, seed=8)
 w = sparse.synthetic_dense(f, k, seed=9)
 print('gated product (k = %d) into packed rows: %.2f ms' % (k, timed(lambda: sparse.gemm_gated_pack(dp, w, gate, 0.5, out=packed))),
       flush=True)
+# the same with seven rows of the small operand in eight all zero (the gradient of a hidden layer is non-zero only
+# at the neighbours of labelled nodes) and the live rows listed: the other rows are emptied without being read
+live = torch.arange(0, n, 8, device=dp.device)
+dp_sparse = torch.zeros_like(dp)
+dp_sparse[live] = dp[live]
+print('gated product, 1 row in 8 listed as live: %.2f ms'
+      % timed(lambda: sparse.gemm_gated_pack(dp_sparse, w, gate, 0.5, out=packed, rows=live)), flush=True)
