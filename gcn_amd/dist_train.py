@@ -78,12 +78,14 @@ class _HiddenThenClassesFn(torch.autograd.Function):
                 and w_next.shape[1] <= sparse.GATED_PACK_MAX_K)
 
     @staticmethod
-    def forward(ctx, plan, p, w_next, keep, out_dropout, chunks, grad_rows=None):
+    def forward(ctx, plan, p, w_next, keep, out_dropout, chunks, grad_rows=None, grad_support=None):
         """``grad_rows`` (ascending int64 row numbers, or None): the gradient that will arrive is zero in every
         other row (the backward product of the logits ran over the labelled nodes' columns: only their neighbours
-        get a non-zero row), so the weight gradient sums over these rows only -- the other terms are zeros."""
+        get a non-zero row), so the weight gradient sums over these rows only -- the other terms are zeros.
+        ``grad_support``: the support restricted to the columns ``grad_rows`` (the entries that meet a non-zero
+        row of this layer's gradient) for the backward product; None: the whole support."""
         h = _product(plan, p, True, chunks, out_dropout)
-        ctx.plan, ctx.keep, ctx.grad_rows = plan, keep, grad_rows
+        ctx.plan, ctx.keep, ctx.grad_rows, ctx.grad_support = plan, keep, grad_rows, grad_support
         ctx.save_for_backward(h, w_next)
         return sparse.gemm(h, w_next)
 
@@ -108,8 +110,10 @@ class _HiddenThenClassesFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # rows of the gradient outside ``rows`` are zero: they come out empty without their gate being read
             packed = sparse.gemm_gated_pack(grad, w_next, h, ctx.keep, rows=rows)
-            d_p = sparse.spmm_packed(ctx.plan.compact, packed)     # symmetric support: rows of A^T are rows of A
-        return None, d_p, d_w, None, None, None, None
+            # symmetric support: rows of A^T are rows of A; the entries that would gather an empty row are left out
+            support = ctx.grad_support if (rows is not None and ctx.grad_support is not None) else ctx.plan.compact
+            d_p = sparse.spmm_packed(support, packed)
+        return None, d_p, d_w, None, None, None, None, None
 
 
 class _ShardDropoutFn(torch.autograd.Function):
@@ -248,6 +252,14 @@ class ShardedGCN(object):
             # the rows of that product's output that can be non-zero: the neighbours of labelled nodes
             lengths = restricted.local.indptr[1:] - restricted.local.indptr[:-1]
             backward.live_rows = torch.nonzero(lengths > 0).reshape(-1).contiguous()
+            # one rank: the support without the columns of the other rows, for the backward product of the layer
+            # before (its gradient is zero in those rows); built once per mask, only where it leaves entries out
+            backward.live_support = None
+            if self.shard.world == 1 and 2 * backward.live_rows.numel() < lengths.numel():
+                live = torch.zeros(self.shard.n_cols, dtype=torch.bool, device=lengths.device)
+                live[backward.live_rows] = True
+                backward.live_support = shard_with_columns(self.shard, live).local
+                del live
             if self.labelled_logits_only == 'backward':       # every logit is formed, as the reference forms them
                 forward = self.plan
             else:
@@ -436,6 +448,8 @@ class ShardedGCN(object):
                   and _HiddenThenClassesFn.usable(self.plan, p, self.weights[li + 1], keep)):
                 ahead = _HiddenThenClassesFn.apply(self.plan, p, self.weights[li + 1], keep, next_drop, self.chunks,
                                                    getattr(logit_plans[1], 'live_rows', None)
+                                                   if logit_plans is not None else None,
+                                                   getattr(logit_plans[1], 'live_support', None)
                                                    if logit_plans is not None else None)
             else:
                 h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop, None,

@@ -574,14 +574,17 @@ def test_products_on_packed_operands_change_nothing(receptive_field, aggregate_f
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
-def test_all_logits_forward_labelled_columns_backward():
+@pytest.mark.parametrize('hidden,labelled_share', [(128, 0.05), (192, 0.002)])
+def test_all_logits_forward_labelled_columns_backward(hidden, labelled_share):
     """ShardedGCN(labelled_logits_only='backward'): every logit is formed as the reference forms them, and the
     backward product of the logits runs over the columns of labelled nodes only (the other rows of the gradient
     are exactly zero).  Against the step that keeps every column: losses and weights equal to rounding (rows cut
-    into chunks are cut elsewhere in the smaller matrix)."""
+    into chunks are cut elsewhere in the smaller matrix).  With 192 hidden units and few labels the zeros go one
+    layer further: the hidden layer's gradient is formed, packed, for the neighbours of labelled nodes only, its
+    weight gradient summed over those rows and its backward product run over their columns."""
     from gcn_amd import dist as gdist, sparse
     from gcn_amd.dist_train import ShardedGCN
-    scale, f_in, hidden, classes = 13, 64, 128, 8
+    scale, f_in, classes = 13, 64, 8
     n = 1 << scale
     indptr, indices = sparse.rmat_csr(scale, 16, seed=42, self_loops=True)
     d = sparse.degree_scale(sparse.row_sums(indptr, None), 'sym')
@@ -590,7 +593,7 @@ def test_all_logits_forward_labelled_columns_backward():
     gen = torch.Generator().manual_seed(5)
     cls = torch.randint(0, classes, (n,), generator=gen)
     labels = torch.nn.functional.one_hot(cls, classes).to(torch.int32).cuda()
-    mask = (torch.rand(n, generator=gen) < 0.05).to(torch.int32).cuda()
+    mask = (torch.rand(n, generator=gen) < labelled_share).to(torch.int32).cuda()
     runs = []
     for mode in ('backward', False):
         shard = gdist.RowShardedCSR.from_full(n, n, indptr, indices, vals, 0, 1)
@@ -600,6 +603,16 @@ def test_all_logits_forward_labelled_columns_backward():
         logits = model.forward(x, train=False)
         assert bool((logits[mask == 0].abs().sum(dim=1) > 0).any())          # unlabelled nodes have logits too
         runs.append((losses, [w.detach().clone() for w in model.weights]))
-    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-6)
+        if mode == 'backward':
+            backward_plan = next(iter(model._grad_plans.values()))[1][1]
+            assert 0 < backward_plan.live_rows.numel() < n
+            # where most nodes have no labelled neighbour the support restricted to the others' columns exists
+            assert (backward_plan.live_support is not None) == (2 * backward_plan.live_rows.numel() < n)
+            if hidden == 192:
+                assert backward_plan.live_support is not None and backward_plan.live_support.nnz < shard.local.nnz
+    assert np.allclose(runs[0][0], runs[1][0], rtol=2e-6)
+    # Adam divides a gradient by its own running magnitude: where a weight's gradient is a sum that nearly cancels
+    # (few labelled nodes), another order of its additions shows in the update as 1e-3 of the step size 0.02
     for a, b in zip(runs[0][1], runs[1][1]):
-        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+        assert float((a - b).abs().mean()) <= 2e-6 * float(b.abs().max())
