@@ -245,9 +245,11 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, c
                         group_world, "(A.X').W0 (no backward product)" if aggregated else "A.(X'.W0)",
                         ', hidden rows formed only where a labelled node reads them' if pruned else '')
                     + ('.  One GPU: the operands that are mostly zeros -- dropout(X) in ms, the hidden layer\'s gradient '
-                       'in reference_order_ms -- are gathered in packed form, and the backward product of the logits in '
-                       'reference_order_ms skips the columns of unlabelled nodes, whose gradient rows are zero (same '
-                       'values, same sums); dense_operands: the same steps with every operand dense and every column kept'
+                       'in reference_order_ms -- are gathered in packed form, and the backward pass of reference_order_ms '
+                       'skips what is exactly zero: the backward product of the logits runs over the columns of labelled '
+                       'nodes, the hidden layer\'s gradient is formed, and its products run, for the neighbours of labelled '
+                       'nodes only (every logit is still formed forward; same values, sums to rounding); dense_operands: '
+                       'the same steps with every operand dense and every row and column kept'
                        if group_world == 1 else
                        '.  N ranks: in ms the rows of X that a shard reads from other ranks are fetched once, before the '
                        'timed steps (X is an input that does not change between steps, like the support), and every step '
