@@ -255,7 +255,8 @@ def rmat_epoch_ms(shard, x_local, group_world, steps=10, warmup=2, hidden=256, c
                        'timed steps (X is an input that does not change between steps, like the support), and every step '
                        'drops own and fetched rows locally by their global row numbers into one packed operand: the first '
                        'layer exchanges nothing; the narrow products of the classes layer exchange their rows every step.  '
-                       'reference_order_ms exchanges the wide rows of X\'.W0 and of the hidden gradient every step'),
+                       'reference_order_ms exchanges the wide rows of X\'.W0 every step, and of the hidden layer\'s gradient the rows of '
+                       'labelled nodes\' neighbours (the others are zero)'),
             'dense_operands': dense}
 
 

@@ -254,6 +254,15 @@ class ShardedGCN(object):
             backward.live_rows = torch.nonzero(lengths > 0).reshape(-1).contiguous()
             # one rank: the support without the columns of the other rows, for the backward product of the layer
             # before (its gradient is zero in those rows); built once per mask, only where it leaves entries out
+            # N ranks: the plan of that layer's backward product over the columns of live rows only -- the rows of
+            # its gradient that are zero are neither exchanged nor multiplied
+            backward.hidden_plan = None
+            if self.shard.world > 1:
+                live_everywhere = torch.empty(self.shard.n_cols, dtype=torch.int32, device=lengths.device)
+                all_gather_rows(live_everywhere, (lengths > 0).to(torch.int32).contiguous(), group=self.group)
+                backward.hidden_plan = HaloPlan(shard_with_columns(self.shard, live_everywhere != 0), group=self.group,
+                                                own_first=self.own_first)
+                del live_everywhere
             backward.live_support = None
             if self.shard.world == 1 and 2 * backward.live_rows.numel() < lengths.numel():
                 live = torch.zeros(self.shard.n_cols, dtype=torch.bool, device=lengths.device)
@@ -452,7 +461,11 @@ class ShardedGCN(object):
                                                    getattr(logit_plans[1], 'live_support', None)
                                                    if logit_plans is not None else None)
             else:
-                h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop, None,
+                # the layer that feeds the classes layer of a training step: its gradient is zero outside the
+                # neighbours of labelled nodes (see _logit_plans)
+                hidden_backward = (getattr(logit_plans[1], 'hidden_plan', None)
+                                   if (logit_plans is not None and li + 1 == last and drop) else None)
+                h = _HaloSpmmFn.apply(self.plan, p, li != last, self.chunks, not drop, next_drop, hidden_backward,
                                       self.packed_operands)
         return h
 
