@@ -95,3 +95,39 @@ def test_product_properties_at_full_size(big, oracle):
     assert bool((s == s[:, :1]).all())
     row_sum = sparse.row_sums(a.indptr, a.values.double())
     assert float((s[:, 0].double() - row_sum).abs().max()) <= 1e-5 * float(row_sum.abs().max())
+
+
+def test_packed_operand_products_at_full_size(big):
+    """The products a training step runs on operands that are mostly zeros, at the headline size: A_hat times
+    dropout(X) gathered in packed form equals, bit for bit, the dense kernel's product with the dropped matrix (its
+    long rows cut where the wide product cuts them) at half and at a quarter kept; the gated gradient formed for a
+    list of rows only equals the one formed for every row."""
+    import torch
+    from gcn_amd import sparse
+    n, a, deg, d = big
+    x = sparse.synthetic_dense(n, F, seed=7)
+    out_dense = torch.empty((n, F), device='cuda')
+    out_packed = torch.empty((n, F), device='cuda')
+    packed = sparse.PackedRows.empty(n, F, x.device)
+    for keep in (0.5, 0.25):
+        dropped = sparse.dropout(x, keep, 5, 1)
+        sparse.dropout_pack(x, keep, 5, 1, out=packed)
+        assert int(packed.kept().sum()) == int((dropped != 0).sum())
+        sparse.spmm(a, dropped, out=out_dense, wide_split=True)
+        sparse.spmm_packed(a, packed, out=out_packed)
+        assert torch.equal(out_dense, out_packed)
+        del dropped
+    # the hidden layer's gradient, non-zero in one row of eight
+    live = torch.arange(0, n, 8, device='cuda')
+    dp = torch.zeros((n, 16), device='cuda')
+    dp[live] = sparse.synthetic_dense(live.numel(), 16, seed=8)
+    w = sparse.synthetic_dense(F, 16, seed=9)
+    gate = torch.clamp(x, min=0)
+    del x
+    every = sparse.gemm_gated_pack(dp, w, gate, 0.5)
+    listed = sparse.gemm_gated_pack(dp, w, gate, 0.5, out=packed, rows=live)
+    assert torch.equal(every.kept(), listed.kept())
+    sparse.spmm_packed(a, every, out=out_dense)
+    sparse.spmm_packed(a, listed, out=out_packed)
+    assert torch.equal(out_dense, out_packed)
+    assert bool((listed.kept()[live] > 0).all())
