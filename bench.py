@@ -496,6 +496,81 @@ def cpu_planetoid_step(name, steps=8):
                       'one thread; first step untimed' % steps}
 
 
+def pubmed_step(with_cpu=True, steps=40):
+    """One optimiser step (forward + backward + Adam, dropout 0.5: the region train.py:203-205 times) of the 2-layer
+    GCN on PubMed -- A_hat from the committed vectors of the reference's own preprocess_adj, 60 labelled nodes,
+    X a seeded synthetic 19,717 x 500 matrix with ~50 entries per row fed as a sparse triple (the dataset's
+    feature file is absent upstream) --, launched kernel by kernel and as one HIP graph; beside it the same step
+    of the CPU oracle on one core."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import gcn_oracle as oracle
+    from gcn_amd import graph as tf
+    from gcn_amd.models import GCN_MLP
+    from gcn_amd.utils import SupportValue, construct_feed_dict
+    fx = np.load(os.path.join(ROOT, 'tests', 'golden', 'pubmed_graph.npz'))
+    n, f_in, classes = int(fx['n']), 500, 3
+    x = oracle.synthetic_dense(n, f_in, seed=19)
+    x = np.where(x > 0.8, x, np.float32(0))
+    r, c = np.nonzero(x)
+    features = SupportValue(np.stack([r, c], 1).astype(np.int32), x[r, c], np.array([n, f_in], dtype=np.int64))
+    support = [SupportValue(fx['hat_indices'], fx['hat_values'], fx['hat_shape'])]
+    rng = np.random.RandomState(8)
+    labels = np.eye(classes)[rng.randint(0, classes, n)]
+    mask = np.zeros(n, dtype=bool)
+    mask[rng.choice(n, 60, replace=False)] = True
+    out = {'dataset': 'pubmed (graph from the reference vectors, synthetic features: %d entries)' % r.size,
+           'labelled': 60, 'steps': steps}
+    for recorded in (False, True):
+        tf.set_random_seed(41)
+        placeholders = {
+            'support': [tf.sparse_placeholder(tf.float32, name='support0')],
+            'features': tf.sparse_placeholder(tf.float32, name='features'),
+            'labels': tf.placeholder(tf.int32, name='labels', shape=(None, classes)),
+            'labels_mask': tf.placeholder(tf.int32, name='labels_mask'),
+            'dropout': tf.placeholder_with_default(0., name='dropout', shape=()),
+            'num_features_nonzero': tf.placeholder(tf.int32, name='num_features_nonzero'),
+        }
+        cfg = {'name': 'gcn', 'connection': ['c', 'c'], 'layer_size': [16], 'conv': 'gcn', 'learning_rate': 0.02,
+               'weight_decay': 5e-4, 'Model': 'GCN', 'dropout': 0.5, 'hip_graph': recorded}
+        model = GCN_MLP(cfg, placeholders, input_dim=f_in)
+        feed = construct_feed_dict(features, support, labels, mask, placeholders)
+        feed[placeholders['dropout']] = 0.5
+        sess = tf.Session()
+        ms = []
+        for step in range(steps + 5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sess.run(model.opt_op, feed_dict=feed)
+            torch.cuda.synchronize()
+            if step >= 5:
+                ms.append((time.perf_counter() - t0) * 1e3)
+        loss = float(sess.run(model.loss, feed_dict=feed))
+        key = 'one_hip_graph' if recorded else 'eager_launches'
+        out[key] = {'epoch_ms': float(np.median(ms)), 'epoch_ms_min': float(np.min(ms)), 'loss_after': loss}
+        del model, sess
+    if with_cpu:
+        ip, ix, v32, _ = oracle.triple_to_csr(fx['hat_indices'], fx['hat_values'], fx['hat_shape'])
+        counts = np.bincount(r, minlength=n)
+        feat = (np.concatenate([[0], np.cumsum(counts)]).astype(np.int64), c.astype(np.int32), x[r, c].astype(np.float32))
+        rs = np.random.RandomState(123)
+        weights = [oracle.glorot((f_in, 16), rs), oracle.glorot((16, classes), rs)]
+        model = oracle.GcnOracle((ip, ix, v32), feat, n, weights)
+        adam = oracle.TfAdam(model.w, 0.02)
+        ms = []
+        for step in range(7):
+            t0 = time.perf_counter()
+            logits = model.forward(dropout=0.5, seed=123, stream_ids=[2 * step, 2 * step + 1])
+            grads = model.backward(logits, labels, mask)
+            adam.step(model.w, grads)
+            if step:
+                ms.append((time.perf_counter() - t0) * 1e3)
+        out['cpu_baseline'] = {'value': float(np.median(ms)), 'min': float(np.min(ms)), 'unit': 'ms per step', 'cores': 1,
+                               'kind': 'port', 'sample': '6 optimiser steps of the oracle (numpy + the C loop of the '
+                                                         'sparse products), one thread; first step untimed'}
+    return out
+
+
 def other_configs(a24, scale, edge_factor, device, with_cpu):
     """The other BASELINE configurations and the narrower widths of the headline graph, timed in this run."""
     from gcn_amd import sparse
@@ -656,6 +731,10 @@ def main():
                     line['gcn_epoch'].append(planetoid_epoch_ms(name, hip_graph=recorded))
                 except Exception as exc:
                     line['gcn_epoch'].append({'dataset': name, 'error': '%s: %s' % (type(exc).__name__, exc)})
+            try:                                  # BASELINE config 2's other dataset
+                line['gcn_epoch'].append(pubmed_step(with_cpu=not args.no_cpu_baseline))
+            except Exception as exc:
+                line['gcn_epoch'].append({'dataset': 'pubmed', 'error': '%s: %s' % (type(exc).__name__, exc)})
             if not args.no_cpu_baseline:
                 # the same step of the CPU oracle on one core, beside the GPU's
                 line['gcn_epoch_cpu_baseline'] = []
