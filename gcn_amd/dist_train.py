@@ -372,7 +372,8 @@ class ShardedGCN(object):
         return hit
 
     def _keeps_feature_halo(self, f):
-        return (self.cache_feature_halo and self.packed_operands and self.shard.world > 1 and self.dropout > 0.0
+        # (a one-rank communicator goes the same way as N ranks, with nothing to fetch)
+        return (self.cache_feature_halo and self.packed_operands and self.dropout > 0.0
                 and 128 < f <= sparse.PackedRows.MAX_F)
 
     def _in_order(self, plan):
