@@ -58,6 +58,19 @@ class _HaloSpmmFn(torch.autograd.Function):
         # symmetric support: rows of A^T are rows of A
         if ctx.pack_grad and plan._identity and 128 < grad.shape[1] <= sparse.PackedRows.MAX_F:
             out = sparse.spmm_packed(plan.compact, sparse.pack_rows(grad))
+        elif (ctx.pack_grad and not plan.own_first and 128 < grad.shape[1] <= sparse.PackedRows.MAX_F
+              and grad.shape[0] == plan.n_first):
+            # N ranks, single-GPU order of additions: own and received rows of the gradient packed into one
+            # operand [own rows | received rows]; the same entries in the same order as the dense two-part product
+            received = plan.exchange(grad)
+            n_own, n_got = plan.n_first, plan.n_remote
+            packed = getattr(plan, '_packed_gradient', None)
+            if packed is None or packed.n_rows != n_own + n_got or packed.f != grad.shape[1]:
+                packed = plan._packed_gradient = sparse.PackedRows.empty(n_own + n_got, grad.shape[1], grad.device)
+            sparse.pack_rows(grad, out=packed.rows(0, n_own))
+            if n_got:
+                sparse.pack_rows(received, out=packed.rows(n_own, n_own + n_got))
+            out = sparse.spmm_packed(plan.compact, packed)
         else:
             out = _product(plan, grad, False, ctx.chunks)
         return None, out, None, None, None, None, None, None

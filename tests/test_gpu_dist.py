@@ -283,6 +283,10 @@ def _train_worker(rank, world, port, result_dir, scale, steps, aggregate_first, 
         if rank == 0:
             np.save(os.path.join(result_dir, 'loss_w%d%s.npy' % (world, tag)), np.array(losses))
             np.save(os.path.join(result_dir, 'w0_w%d%s.npy' % (world, tag)), model.weights[0].detach().cpu().numpy())
+            if (world > 1 and model_options.get('labelled_logits_only') == 'backward' and 128 < hidden <= 256
+                    and not own_first):
+                hidden_plan = next(iter(model._grad_plans.values()))[1][1].hidden_plan
+                assert hidden_plan._packed_gradient.n_rows == hidden_plan.n_first + hidden_plan.n_remote
             if world > 1 and model_options.get('cache_feature_halo', True) and 128 < f_in <= 256 and aggregate_first:
                 assert len(model._feature_halos) == 1          # one exchange of feature rows, at the first step
     finally:
@@ -356,13 +360,15 @@ def _train_worker_kw(rank, world, port, result_dir, scale, steps, own_first, opt
     _train_worker(rank, world, port, result_dir, scale, steps, True, own_first, **options)
 
 
-def test_reference_order_step_with_labelled_columns_backward_on_two_ranks(tmp_path):
+@pytest.mark.parametrize('widths', [(32, 128), (64, 192)])
+def test_reference_order_step_with_labelled_columns_backward_on_two_ranks(tmp_path, widths):
     """The reference's order of operations on 2 ranks in the form the bench line times: every logit formed, the
-    backward product of the logits over the columns of labelled nodes only (a smaller support, a smaller exchange).
-    Against 1 rank in the same form."""
+    backward product of the logits over the columns of labelled nodes only (a smaller support, a smaller exchange),
+    the hidden layer's backward product over the columns of their neighbours only -- and, with 192 hidden units,
+    on own and received rows of the gradient packed into one operand.  Against 1 rank in the same form."""
     scale, steps = 13, 3
-    port = 30500 + (os.getpid() % 1000)
-    form = dict(receptive_field=False, labelled_logits_only='backward')
+    port = 30500 + (os.getpid() % 1000) + widths[1]
+    form = dict(receptive_field=False, labelled_logits_only='backward', widths=widths)
     _train_worker(0, 1, port, str(tmp_path), scale, steps, False, **form)
     mp.start_processes(_train_worker_kw_ref, args=(2, port + 1, str(tmp_path), scale, steps, form), nprocs=2, join=True,
                        start_method='spawn')
