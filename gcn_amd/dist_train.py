@@ -273,8 +273,11 @@ class ShardedGCN(object):
             if self.shard.world > 1:
                 live_everywhere = torch.empty(self.shard.n_cols, dtype=torch.int32, device=lengths.device)
                 all_gather_rows(live_everywhere, (lengths > 0).to(torch.int32).contiguous(), group=self.group)
+                # a gradient that will be gathered packed keeps the single-GPU order of additions: its exchange is
+                # small (live rows only), there is little for own rows to hide
+                packs = self.packed_operands and 128 < self.weights[-1].shape[0] <= sparse.PackedRows.MAX_F
                 backward.hidden_plan = HaloPlan(shard_with_columns(self.shard, live_everywhere != 0), group=self.group,
-                                                own_first=self.own_first)
+                                                own_first=False if packs else self.own_first)
                 del live_everywhere
             backward.live_support = None
             if self.shard.world == 1 and 2 * backward.live_rows.numel() < lengths.numel():
