@@ -652,14 +652,36 @@ def main():
         nnz = int(t.item())
         torch.cuda.empty_cache()
         own_first = False if args.in_order else 'auto'
-        op = (gdist.HaloSpmm(shard, f, chunks=args.chunks, own_first=own_first) if not args.allgather
-              else gdist.AllGatherSpmm(shard, f))
+        tuned = None
+        if args.allgather:
+            op = gdist.AllGatherSpmm(shard, f)
+        elif args.no_autotune or args.in_order or world == 1:
+            op = gdist.HaloSpmm(shard, f, chunks=args.chunks, own_first=own_first)
+            if not args.no_autotune:
+                tuned = [(r, t, op.plan.own_first) for r, t in op.autotune(b_local)]
+        else:
+            # Which form pipelines best depends on what the links of THIS node deliver beside the product: both
+            # orders of additions (single-GPU order; own rows first, which hides the exchange behind work that
+            # needs none) and every candidate split of the feature columns are timed once on this communicator --
+            # maximum over the ranks, so every rank takes the same decision -- and the fastest is kept.
+            tuned, best = [], None
+            for first in (False, True):
+                cand = gdist.HaloSpmm(shard, f, chunks=args.chunks, own_first=first)
+                timings = cand.autotune(b_local)
+                tuned += [(r, t, first) for r, t in timings]
+                fastest = min(t for _, t in timings)
+                if best is None or fastest < best[0]:
+                    if best is not None:
+                        best[1].plan.drop_buffers()
+                    best = (fastest, cand)
+                else:
+                    cand.plan.drop_buffers()
+                del cand
+                torch.cuda.empty_cache()
+            op = best[1]
+            del best
         # the matrix whose kernel the roofline entry times: the one the step's last launch multiplies
         a = op.plan.matrices[-1] if not args.allgather else shard.local
-        tuned = None
-        if not args.allgather and not args.no_autotune:
-            # which split of the feature columns pipelines best on this communicator: measured once
-            tuned = op.autotune(b_local)
         a.plan.set_timing(True)
 
         def step():
@@ -717,7 +739,8 @@ def main():
                          'traffic': None,
                          'kernel': 'spmm_rows_kernel', 'kernel_ms': row_ms, 'reduce_kernel_ms': red_ms,
                          'algorithmic_bytes': local_min, 'launch_features': f_launch},
-            'pipeline_candidates_ms': ([{'ranges': r, 'ms': t} for r, t in tuned] if (sharded and tuned) else None),
+            'pipeline_candidates_ms': ([{'ranges': r, 'ms': t, 'own_rows_first': o} for r, t, o in tuned]
+                                       if (sharded and tuned) else None),
         }
         if not sharded and not args.no_cpu_baseline:
             base, allcores, check = cpu_baseline(a, b_full, c, args.cpu_row_stride)
@@ -756,6 +779,8 @@ def main():
             line['roofline']['traffic_source'] = rec['source']
             line['l2_miss_traffic_gbps'] = rec['l2_miss_bytes_per_launch'] / (row_ms * 1e-3) / 1e9
     ranges_used = list(op.ranges) if (sharded and not args.allgather) else None
+    # the training step takes the order of additions the product's measurement picked
+    epoch_own_first = bool(op.plan.own_first) if (sharded and not args.allgather) else False
     # GCN epoch on the same graph, every rank takes part
     epoch = None
     printed = threading.Lock()
@@ -782,8 +807,7 @@ def main():
             shares = args.chunks
             if sharded and not args.allgather:
                 shares = tuple(hi - lo for lo, hi in ranges_used)
-            epoch = rmat_epoch_ms(shard, b_local, world, chunks=shares,
-                                  own_first=bool(sharded and not args.allgather and not args.in_order) and 'auto')
+            epoch = rmat_epoch_ms(shard, b_local, world, chunks=shares, own_first=epoch_own_first)
         except Exception as exc:            # the product's line above stays valid whatever happens here
             epoch = {'error': '%s: %s' % (type(exc).__name__, exc)}
     if watchdog is not None:

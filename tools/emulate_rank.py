@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gcn_amd import sparse, dist as gdist   # noqa: E402
 
 LINK_GBPS = 153.0
+LINK_RATES = (153.0, 100.0, 64.0, 48.0)      # GB/s per link and direction the timeline is also evaluated at
 
 
 def timed(fn, reps=8):
@@ -113,8 +114,16 @@ def own_first_report(world, plan, b_local, out, halo, t1, links, recv_rows, f):
             sent += link[i]
             arrivals.append(sent)
             done = max(done, sent) + t_each[i] * slowdown
+        at_rate = {}
+        for rate in LINK_RATES:
+            sent_r, done_r = t_pack0, t_own * slowdown
+            for i in range(len(ranges)):
+                sent_r += link[i] * LINK_GBPS / rate
+                done_r = max(done_r, sent_r) + t_each[i] * slowdown
+            at_rate[str(rate)] = t1 / (world * done_r)
         rows.append({'widths': widths, 'own_ms': t_own, 'remote_ms': t_each, 'pipeline_ms': t_pipe, 'slowdown': slowdown,
-                     'arrival_ms': arrivals, 'modelled_step_ms': done, 'modelled_efficiency': t1 / (world * done)})
+                     'arrival_ms': arrivals, 'modelled_step_ms': done, 'modelled_efficiency': t1 / (world * done),
+                     'efficiency_at_link_gbps': at_rate})
         print('world %d own-first widths %-28s own %.2f + remote %s = %.2f  pipeline %.2f  slowdown %.3f  arrivals %s -> T_P %.2f ms, E = %.3f'
               % (world, widths, t_own, ['%.2f' % t for t in t_each], t_own + sum(t_each), t_pipe, slowdown,
                  ['%.2f' % t for t in arrivals], done, t1 / (world * done)), flush=True)
@@ -193,10 +202,18 @@ def main():
                 arrivals.append(sent)
                 done = max(done, sent) + t_each[i] * slowdown
             modelled = done
+            # the same timeline at other link rates (what a collective achieves per link is below the nominal rate)
+            at_rate = {}
+            for rate in LINK_RATES:
+                sent_r, done_r = t_pack[0], 0.0
+                for i in range(len(ranges)):
+                    sent_r += link[i] * LINK_GBPS / rate
+                    done_r = max(done_r, sent_r) + t_each[i] * slowdown
+                at_rate[str(rate)] = t1 / (world * done_r)
             entry['splits'].append({'widths': widths, 'product_ms': t_each, 'pipeline_ms': t_pipe, 'pack_ms': t_pack,
                                     'copy_ms': t_copy, 'link_ms': link, 'arrival_ms': arrivals,
                                     'slowdown_beside_exchange': slowdown, 'modelled_step_ms': modelled,
-                                    'modelled_efficiency': t1 / (world * modelled)})
+                                    'modelled_efficiency': t1 / (world * modelled), 'efficiency_at_link_gbps': at_rate})
             print('world %d widths %-20s products %s = %.2f  pipeline %.2f  slowdown %.3f  arrivals %s -> T_P %.2f ms, E = %.3f'
                   % (world, widths, ['%.2f' % t for t in t_each], sum(t_each), t_pipe, slowdown,
                      ['%.2f' % t for t in arrivals], modelled, t1 / (world * modelled)), flush=True)
@@ -205,12 +222,20 @@ def main():
         if args.own_first:
             best = min(entry['own_first'], key=lambda s_: s_['modelled_step_ms'])
             print('world %d own-first best %s: E = %.3f' % (world, best['widths'], best['modelled_efficiency']), flush=True)
+            for rate in LINK_RATES:
+                top = max(entry['own_first'], key=lambda s_: s_['efficiency_at_link_gbps'][str(rate)])
+                print('world %d own-first at %.0f GB/s per link: best %s E = %.3f'
+                      % (world, rate, top['widths'], top['efficiency_at_link_gbps'][str(rate)]), flush=True)
             report['worlds'].append(entry)
             del shard, plan, halo, out, b_local
             torch.cuda.empty_cache()
             continue
         best = min(entry['splits'], key=lambda s_: s_['modelled_step_ms'])
         entry['best'] = best
+        for rate in LINK_RATES:
+            top = max(entry['splits'], key=lambda s_: s_['efficiency_at_link_gbps'][str(rate)])
+            print('world %d in order at %.0f GB/s per link: best %s E = %.3f'
+                  % (world, rate, top['widths'], top['efficiency_at_link_gbps'][str(rate)]), flush=True)
         report['worlds'].append(entry)
         print('world %d: references %.1f%% of N, full-width local product %.2f ms, links busy %.2f ms per product; '
               'best split %s: E(%d) = %.3f' % (world, 100.0 * (own + plan.n_remote) / n, t_full, entry['link_total_ms'],
