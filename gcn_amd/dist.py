@@ -458,7 +458,9 @@ class HaloSpmm(object):
     # width shares of the candidate pipelines: how long the first (exposed) exchange is against how
     # much the narrower products cost depends on the ratio of link to memory speed, which differs
     # between 2, 4 and 8 ranks -- so it is measured, not assumed
-    CANDIDATES = ((1,), (1, 7), (1, 3), (1, 1), (1, 1, 6), (1, 2, 5), (1, 1, 2), (1, 1, 2, 4), (2, 3, 4, 7))
+    # (the equal splits in four and eight win where the links are slow: the products then wait for rows anyway)
+    CANDIDATES = ((1,), (1, 7), (1, 3), (1, 1), (1, 1, 6), (1, 2, 5), (1, 1, 2), (1, 1, 2, 4), (2, 3, 4, 7),
+                  (1, 1, 1, 1), (1, 1, 1, 1, 1, 1, 1, 1))
 
     def autotune(self, b_local, reps=2, clock=None):
         """Time every candidate split of the feature columns on this communicator (max over the ranks,

@@ -99,7 +99,7 @@ def own_first_report(world, plan, b_local, out, halo, t1, links, recv_rows, f):
     print('world %d own-first: own part %d entries %.2f ms, remote part %d entries' % (world, a_own.nnz, t_own, a_remote.nnz),
           flush=True)
     rows = []
-    for shares in gdist.HaloSpmm.CANDIDATES + ((1, 1, 1, 1), (1, 1, 1, 1, 1, 1, 1, 1)):
+    for shares in gdist.HaloSpmm.CANDIDATES:
         ranges = gdist.column_shares(f, shares)
         widths = [hi - lo for lo, hi in ranges]
         t_each = [timed(lambda lo=lo, hi=hi: sparse.spmm_add(a_remote, halo[:, lo:hi], out[:, lo:hi], out=out[:, lo:hi],
