@@ -235,3 +235,31 @@ def test_gated_gradient_for_listed_rows_only(oracle):
     assert torch.equal(sparse.gemm_gated_pack(a, b, gate, 0.5, out=stale, rows=padded).dense(), whole.dense())
     none = sparse.gemm_gated_pack(a, b, gate, 0.5, out=stale, rows=rows[:0])
     assert bool((none.dense() == 0).all()) and int(none.kept().sum()) == 0
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3, 4])
+def test_packed_product_on_random_row_length_mixes(oracle, seed):
+    """Random matrices with heavy-tailed row lengths (many empty and one-entry rows, some beyond the split threshold),
+    random widths and densities: the packed product equals the dense kernel's, bit for bit, and the CPU loop on every
+    row it sums serially."""
+    import torch
+    from gcn_amd import sparse
+    rng = np.random.RandomState(100 + seed)
+    n_rows, n_cols = int(rng.randint(2000, 9000)), int(rng.randint(3000, 12000))
+    lengths = np.minimum((rng.pareto(0.9, size=n_rows) * 2).astype(np.int64), n_cols)
+    lengths[rng.rand(n_rows) < 0.2] = 0
+    lengths[rng.randint(0, n_rows, size=3)] = rng.randint(1025, min(n_cols, 3000), size=3)
+    indptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n_cols, size=int(k), replace=False)) if k else np.zeros(0, np.int64)
+                              for k in lengths]).astype(np.int32)
+    vals = rng.uniform(-1, 1, size=indices.size).astype(np.float32)
+    a = sparse.DeviceCSR(n_rows, n_cols, torch.as_tensor(indptr).cuda(), torch.as_tensor(indices).cuda(),
+                         torch.as_tensor(vals).cuda())
+    f = int(rng.choice([256, 255, 200, 129, 64, 17]))
+    b = _sparse_dense(n_cols, f, float(rng.choice([0.05, 0.25, 0.5, 0.9])), seed=seed)
+    got = sparse.spmm_packed(a, sparse.pack_rows(b), relu=bool(seed & 1))
+    want = sparse.spmm(a, b, wide_split=True, relu=bool(seed & 1))
+    assert torch.equal(got, want)
+    cpu = oracle.spmm_csr(indptr, indices, vals, b.cpu().numpy(), relu=bool(seed & 1))
+    short = lengths <= 1024
+    assert np.array_equal(got.cpu().numpy()[short], cpu[short])
